@@ -1,0 +1,158 @@
+"""Seeded generators of boundary-heavy test inputs (features, BAM-record dicts, whitelists).
+
+Schemas: see oracle/ref_harness.py.  Coordinates are deliberately concentrated on the
+10 kb bucket boundaries (k*bs, k*bs +- 1) and on the lengths {1,2,50,300,5000,bs-1,bs,
+bs+1,25000} that the survey's probes used.
+"""
+
+import random
+
+BS = 10000
+LENGTHS = [1, 2, 3, 50, 100, 300, 5000, BS - 1, BS, BS + 1, 25000]
+TYPES = ['protein_coding', 'lncRNA', 'lincRNA', 'TE', 'TE', 'TE', 'snRNA', 'miRNA']
+INDEX_CHROMS = ['chr1', 'chr2', 'chrX', 'chrM', '7']
+READ_CHROMS = ['chr1', 'chr2', 'chrX', 'chrM', '7', 'chr7', 'chrUn_x', 'chr1_random', 'chr2', 'chr1']
+MAPQS = [0, 1, 3, 19, 20, 21, 60, 255, 255, 255, 255, 255]
+
+
+def _coord(rng, span):
+    k = rng.randrange(0, span // BS)
+    mode = rng.random()
+    if mode < 0.45:
+        return max(0, k * BS + rng.choice([-2, -1, 0, 1, 2]))
+    return rng.randrange(0, span)
+
+
+def make_features(seed, n, span=200000, types=None, chroms=None, with_strand=True):
+    rng = random.Random(seed)
+    types = types or TYPES
+    chroms = chroms or INDEX_CHROMS
+    n_genes = max(3, n // 6)
+    n_tes = max(3, n // 10)
+    feats = []
+    for _ in range(n):
+        t = rng.choice(types)
+        left = _coord(rng, span)
+        right = left + rng.choice(LENGTHS) - (1 if rng.random() < 0.3 else 0)
+        if t == 'TE':
+            k = rng.randrange(n_tes)
+            ensg = 'LINE:L1:L1Md_%d' % k if k % 2 else 'SINE:Alu:AluY%d' % k
+            name = ensg
+        else:
+            k = rng.randrange(n_genes)
+            ensg = 'ENSG%011d' % k
+            name = 'Gene%d' % k
+        f = {'chr': rng.choice(chroms), 'left': left, 'right': right, 'name': name, 'type': t, 'ensg': ensg}
+        if with_strand:
+            f['strand'] = rng.choice(['+', '-'])
+        feats.append(f)
+    return feats
+
+
+def _flag(rng):
+    f = 0
+    x = rng.random()
+    if x < 0.03:
+        f |= 0x4
+    elif x < 0.06:
+        f |= 0x400
+    elif x < 0.08:
+        f |= 0x200
+    if rng.random() < 0.1:
+        f |= 0x100
+    if rng.random() < 0.05:
+        f |= 0x800
+    if rng.random() < 0.5:
+        f |= 0x10
+    return f
+
+
+def make_records(seed, n, features=None, span=200000, paired=False):
+    """n BAM records.  ~60 % are anchored on a feature edge (if features given)."""
+    rng = random.Random(seed)
+    recs = []
+    for i in range(n):
+        if features and rng.random() < 0.6:
+            f = rng.choice(features)
+            anchor = rng.choice([f['left'], f['right']]) + rng.choice([-2, -1, 0, 1, 2])
+            ln = rng.choice(LENGTHS)
+            pos = max(0, anchor - (ln if rng.random() < 0.5 else 0))
+            rname = 'chr' + str(f['chr']).replace('chr', '') if rng.random() < 0.9 else rng.choice(READ_CHROMS)
+        else:
+            pos = _coord(rng, span)
+            ln = rng.choice(LENGTHS)
+            rname = rng.choice(READ_CHROMS)
+        qn = 'r%d' % (i // 2 if paired else i)
+        recs.append({'flag': _flag(rng), 'mapq': rng.choice(MAPQS), 'qname': qn, 'rname': rname,
+                     'pos': pos, 'end': pos + ln})
+    return recs
+
+
+def make_whitelist(seed, n, length=16):
+    rng = random.Random(seed)
+    s = set()
+    while len(s) < n:
+        s.add(''.join(rng.choice('ACGT') for _ in range(length)))
+    wl = sorted(s)
+    rng.shuffle(wl)
+    return wl
+
+
+def make_sc_records(seed, n, whitelist, features=None, span=200000, n_cells=12, umi_len=10,
+                    reads_per_umi=3, second_class_frac=0.05, stranded=False):
+    """10x-style SE records inside the reference's determinism envelope:
+    every (CB,UB) key stays on one (chrom[,strand]) class, except that a fraction receives
+    exactly one read of a second class as its LAST read."""
+    rng = random.Random(seed)
+    cells = [rng.choice(whitelist) for _ in range(n_cells)]
+    weights = [1.0 / (i + 1) for i in range(n_cells)]
+    groups = []
+    made = 0
+    while made < n:
+        cb = rng.choices(cells, weights)[0]
+        if rng.random() < 0.04:
+            cb = cb[:-1] + ('A' if cb[-1] != 'A' else 'C')  # mostly off-whitelist
+        ub = ''.join(rng.choice('ACGT' if rng.random() < 0.97 else 'ACGTN') for _ in range(umi_len))
+        if features and rng.random() < 0.7:
+            f = rng.choice(features)
+            anchor = rng.choice([f['left'], f['right']]) + rng.choice([-2, -1, 0, 1, 2])
+            ln = rng.choice([50, 98, 100, 300, 5000])
+            pos = max(0, anchor - (ln if rng.random() < 0.5 else 0))
+            rname = 'chr' + str(f['chr']).replace('chr', '')
+        else:
+            pos = _coord(rng, span)
+            ln = rng.choice([50, 98, 100])
+            rname = rng.choice(READ_CHROMS)
+        rev = rng.random() < 0.5
+        k = 1 + int(rng.expovariate(1.0 / reads_per_umi))
+        grp = []
+        for _ in range(k):
+            p = max(0, pos + rng.choice([-3, -2, -1, 0, 1, 2, 3]))
+            fl = (_flag(rng) & ~0x10) | (0x10 if rev else 0)
+            grp.append({'flag': fl, 'mapq': rng.choice(MAPQS), 'rname': rname, 'pos': p, 'end': p + ln,
+                        'tags': {'CB': cb, 'UB': ub}})
+        if rng.random() < second_class_frac:
+            other = rng.choice([c for c in ['chr1', 'chr2', 'chrX'] if c != rname] or ['chr2'])
+            p = _coord(rng, span)
+            grp.append({'flag': (0x10 if rev else 0), 'mapq': 255, 'rname': other, 'pos': p, 'end': p + 100,
+                        'tags': {'CB': cb, 'UB': ub}, '_last': True})
+        groups.append(grp)
+        made += len(grp)
+    # interleave groups while keeping each group's internal order (and '_last' reads last)
+    cursors = [0] * len(groups)
+    live = list(range(len(groups)))
+    recs = []
+    while live:
+        gi = rng.choice(live[:50])
+        g = groups[gi]
+        r = dict(g[cursors[gi]])
+        r.pop('_last', None)
+        r['qname'] = 'q%d' % len(recs)
+        # use CR/UR instead of CB/UB now and then (te_count.py:404-410, 421-427)
+        if rng.random() < 0.05:
+            r['tags'] = {'CR': r['tags']['CB'], 'UR': r['tags']['UB']}
+        recs.append(r)
+        cursors[gi] += 1
+        if cursors[gi] == len(g):
+            live.remove(gi)
+    return recs[:n] if len(recs) > n else recs
