@@ -1,0 +1,155 @@
+/*
+ * tecount.h -- C ABI of libtecount.so: the MI355X (gfx950) read-vs-annotation overlap counter.
+ *
+ * The reference (oaxiom/te_counter) has no FFI seam: its hot path is three Python methods of
+ * one class, measureTE.parse_bamse / parse_bampe / sc_parse_bamse (te_count/te_count.py:167,
+ * 42, 298), called from bin/te_count:98-120.  The entry points below are what a binding of that
+ * path would bind; each one names the reference code it replaces.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every call returns 0 on success and a negative TEC_E* code on failure; tec_last_error()
+ *     gives the message.  Nothing throws across the boundary.
+ *   - "host" pointers are ordinary (ideally pinned, see tec_alloc_pinned) memory; "device"
+ *     pointers are HBM addresses on the context's GPU.
+ *   - a context is single-producer (one thread submits); calls drop no locks of the caller.
+ *   - coordinates are the BAM/pysam ones the reference uses verbatim: 0-based reference_start,
+ *     reference_end one past the last aligned base; annotation left/right exactly as stored in
+ *     the index (no conversion, te_count/miniglbase/location.py:31).
+ */
+#ifndef TECOUNT_H
+#define TECOUNT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEC_VERSION 100 /* 0.1.0 */
+
+#define TEC_OK 0
+#define TEC_EINVAL -1   /* bad argument / call order */
+#define TEC_EHIP -2     /* a HIP runtime call failed */
+#define TEC_ENOMEM -3
+#define TEC_ESTATE -4   /* e.g. submit before begin, no index uploaded */
+#define TEC_EENHANCER -5 /* bulk: a read whose only countable type is 'enhancer'; the reference
+                            dies with NameError there (te_count.py:145-147, 258-260) */
+#define TEC_EOVERFLOW -6
+
+/* The reference's bucket width: a semantic constant (te_count/miniglbase/config.py:36). */
+#define TEC_BUCKET_SIZE 10000
+
+/* Feature classes, derived by the host from the index's `type` strings.  Which classes count
+ * where: te_count.py:134-147 / 247-260 (bulk), 662-684 (single cell). */
+#define TEC_CLASS_OTHER 0    /* e.g. miRNA: can make a read "assigned" but never counts      */
+#define TEC_CLASS_GENE 1     /* protein_coding | lincRNA | lncRNA                            */
+#define TEC_CLASS_TE 2
+#define TEC_CLASS_SNRNA 3    /* counted in bulk, not in single cell                          */
+#define TEC_CLASS_ENHANCER 4 /* crashes bulk, counted in single cell                         */
+
+/* meta word of a feature: name id | class << 26 | strand id << 29 */
+#define TEC_META_NAME_BITS 26
+#define TEC_META_CLASS_SHIFT 26
+#define TEC_META_STRAND_SHIFT 29
+#define TEC_STRAND_PLUS 0  /* '+' */
+#define TEC_STRAND_MINUS 1 /* '-' */
+                           /* 2..7: any other strand string, one id per distinct string */
+
+/* Record flag bits the path looks at (SAM spec; pysam is_unmapped / is_qcfail / is_duplicate /
+ * is_reverse, te_count.py:81-86, 204, 394, 438). */
+#define TEC_FLAG_UNMAPPED 0x4
+#define TEC_FLAG_REVERSE 0x10
+#define TEC_FLAG_QCFAIL 0x200
+#define TEC_FLAG_DUP 0x400
+
+typedef struct tec_ctx tec_ctx;
+
+/* Log-only counters of the bulk loops (te_count.py:158-162, 269-274). */
+typedef struct tec_stats {
+    uint64_t units;     /* records (SE) or pairs (PE) submitted                                   */
+    uint64_t assigned;  /* "Reads were assigned to a gene"                                        */
+    uint64_t lowq;      /* "Read quality is too low"                                              */
+    uint64_t badchrom;  /* "Reads mapped to an invalid chromosome"                                */
+    uint64_t qcfail;    /* "Reads are QC fails"                                                   */
+} tec_stats;
+
+int tec_version(void);
+/* Message of the last failure on this context (ctx == NULL: of the last failed tec_create). */
+const char* tec_last_error(const tec_ctx* ctx);
+
+/* One context per GPU.  device_id is a HIP device ordinal. */
+int tec_create(int device_id, tec_ctx** out);
+void tec_destroy(tec_ctx* ctx);
+
+/* Page-locked host memory for the SoA batches (so that hipMemcpyAsync really is async). */
+int tec_alloc_pinned(tec_ctx* ctx, size_t bytes, void** out);
+int tec_free_pinned(tec_ctx* ctx, void* p);
+
+/* ---- Index -------------------------------------------------------------------------------
+ * Replaces the unpickled genelist (`self.genome.buckets` / `.linearData`) that the reference
+ * loops reach into (te_count.py:31-35, 68-73, 100-126; built by
+ * te_count/miniglbase/genelist.py:332-396).
+ *
+ * Input: one row per annotation feature, in any order.  chrom_id indexes the caller's table of
+ * index-side chromosome keys (0 <= chrom_id < n_chrom).  The library builds, on the host, a
+ * per-chromosome CSR over fine bins of 2^bin_shift bp (entries = {left, right, meta}) and
+ * uploads it to HBM.  The reference's 10 kb "is this feature a candidate" rule is evaluated in
+ * closed form per entry on the device, so the result is independent of bin_shift.
+ * bin_shift == 0 lets the library choose.
+ */
+int tec_index_build(tec_ctx* ctx, uint64_t n_features, const int32_t* chrom_id, const int32_t* left,
+                    const int32_t* right, const uint32_t* meta, uint32_t n_chrom, uint32_t n_names,
+                    int bin_shift);
+/* Facts about the resident index (any pointer may be NULL). */
+int tec_index_info(const tec_ctx* ctx, uint64_t* n_entries, uint64_t* n_bins, int* bin_shift,
+                   uint64_t* device_bytes);
+
+/* ---- Bulk counting -----------------------------------------------------------------------
+ * Replaces the `while 1:` loops of parse_bamse (te_count.py:201-263) and parse_bampe
+ * (te_count.py:76-152).  A "unit" is one record (SE) or one pair of consecutive records (PE);
+ * the host decoder has already
+ *   - mapped the read's chromosome to an index chrom id, -1 if
+ *     reference_name.replace('chr','') is not an index key (te_count.py:96-102, 212-218);
+ *   - set p1 = reference_start, p2 = reference_end (SE, te_count.py:213-214) or
+ *     p1 = read1.reference_start, p2 = read2.reference_start (PE, te_count.py:97-98);
+ *   - PE: OR-ed both mates' flags into `flag` and taken read1's mapq (te_count.py:81-88).
+ * The unit layout is therefore the same for SE and PE: 15 bytes per unit.
+ */
+int tec_bulk_begin(tec_ctx* ctx, int mapq_min);
+
+/* Host SoA batch -> HBM (hipMemcpyAsync on the context's copy stream) -> count kernel.
+ * Returns as soon as the work is queued.  *ticket (optional) identifies the batch: the host
+ * buffers may be overwritten once tec_bulk_wait(ctx, ticket) has returned. */
+int tec_bulk_submit(tec_ctx* ctx, uint64_t n_units, const int32_t* chrom_id, const int32_t* p1,
+                    const int32_t* p2, const uint16_t* flag, const uint8_t* mapq, uint64_t* ticket);
+int tec_bulk_wait(tec_ctx* ctx, uint64_t ticket);
+
+/* Same, for a batch that is already resident in HBM (device pointers); no copy is made and the
+ * buffers must stay valid until tec_bulk_sync / tec_bulk_finish. */
+int tec_bulk_submit_device(tec_ctx* ctx, uint64_t n_units, const int32_t* d_chrom_id, const int32_t* d_p1,
+                           const int32_t* d_p2, const uint16_t* d_flag, const uint8_t* d_mapq);
+
+/* Wait for everything submitted so far. */
+int tec_bulk_sync(tec_ctx* ctx);
+
+/* Device address of the running uint64 count vector (n_names entries, index = name id) and of
+ * the 5-word stats block {units, assigned, lowq, badchrom, qcfail}; for the caller's multi-GPU
+ * sum-reduce (RCCL through torch.distributed).  Valid until tec_destroy / the next
+ * tec_index_build. */
+int tec_bulk_device_buffers(tec_ctx* ctx, void** d_counts, void** d_stats);
+
+/* Drain, then copy counts (n_names uint64) and stats to the host.  Returns TEC_EENHANCER if any
+ * read hit only 'enhancer'-class features (counts are still delivered).  The count vector is
+ * what final_results holds when the reference loop ends (te_count.py:165, 277), keyed by name
+ * id instead of by string. */
+int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats);
+
+/* Duration (ms, HIP events on the stream the kernel runs on) and number of count-kernel
+ * launches since tec_bulk_begin; for bench.py's roofline figure. */
+int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TECOUNT_H */

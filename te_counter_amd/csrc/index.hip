@@ -1,0 +1,184 @@
+// Host-side build of the flat HBM interval index and its upload.
+//
+// Replaces genelist._optimiseData (te_count/miniglbase/genelist.py:332-396), which files every
+// feature under each 10 kb bucket it touches, and the `loc_lookups` table the reference loops
+// build per run (te_count/te_count.py:70-73, 195-198, 588-590).
+//
+// Layout (all chromosomes concatenated, one blob in HBM):
+//   bin_off[n_bins + 1]   u32 CSR offsets; a chromosome's fine bins are contiguous
+//   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by name id inside a fine bin
+//   chrom_base[n_chrom], chrom_nbins[n_chrom]
+// A feature [left, right] is filed under every fine bin (2^shift bp) that intersects
+// [left-1, right+1]: any read edge that can pass one of the reference's 2-bp edge tests
+// (te_count.py:122,125 / 237,240 / 645,648) then finds the feature in the ONE fine bin of that
+// edge position.  Whether the reference would have looked at the feature at all (its 10 kb
+// bucket-candidate rule) is decided on the device from left/right, see bulk.hip.
+#include <algorithm>
+#include <cstring>
+
+#include "tecount_internal.h"
+
+namespace {
+
+constexpr int kMinShift = 7;
+constexpr int kMaxShift = 20;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Coverage of a feature in bp, or false if no edge test can ever pass for it.
+inline bool coverage(int32_t gl, int32_t gr, int64_t* lo, int64_t* hi) {
+    if ((int64_t)gr < (int64_t)gl - 1) return false;
+    *lo = gl > 0 ? (int64_t)gl - 1 : 0;
+    *hi = (int64_t)gr + 1;
+    return *hi >= 0;
+}
+
+}  // namespace
+
+extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id, const int32_t* left,
+                               const int32_t* right, const uint32_t* meta, uint32_t n_chrom, uint32_t n_names,
+                               int bin_shift) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_index_build: NULL context");
+    if (ctx->bulk_open) return tec_fail(ctx, TEC_ESTATE, "tec_index_build: a bulk run is open");
+    if (n && (!chrom_id || !left || !right || !meta)) return tec_fail(ctx, TEC_EINVAL, "tec_index_build: NULL array");
+    if (n_chrom == 0 || n_names == 0) return tec_fail(ctx, TEC_EINVAL, "tec_index_build: empty chromosome or name table");
+    if (n_names > (1u << TEC_META_NAME_BITS))
+        return tec_fail(ctx, TEC_EINVAL, "tec_index_build: %u names exceed the %d-bit name id", n_names, TEC_META_NAME_BITS);
+    if (bin_shift != 0 && (bin_shift < kMinShift || bin_shift > kMaxShift))
+        return tec_fail(ctx, TEC_EINVAL, "tec_index_build: bin_shift %d outside [%d, %d]", bin_shift, kMinShift, kMaxShift);
+
+    // pass 1: validate, per-chromosome extent, entry totals for every candidate shift
+    std::vector<int64_t> chrom_hi(n_chrom, -1);
+    uint64_t entries_at[kMaxShift + 1] = {0};
+    uint64_t hittable = 0;
+    uint32_t class_mask = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (chrom_id[i] < 0 || (uint32_t)chrom_id[i] >= n_chrom)
+            return tec_fail(ctx, TEC_EINVAL, "tec_index_build: feature %llu has chrom id %d", (unsigned long long)i, chrom_id[i]);
+        if (left[i] < 0) return tec_fail(ctx, TEC_EINVAL, "tec_index_build: feature %llu has a negative left", (unsigned long long)i);
+        if ((meta[i] & ((1u << TEC_META_NAME_BITS) - 1)) >= n_names)
+            return tec_fail(ctx, TEC_EINVAL, "tec_index_build: feature %llu has name id >= n_names", (unsigned long long)i);
+        class_mask |= 1u << ((meta[i] >> TEC_META_CLASS_SHIFT) & 7u);
+        int64_t lo, hi;
+        if (!coverage(left[i], right[i], &lo, &hi)) continue;
+        ++hittable;
+        chrom_hi[chrom_id[i]] = std::max(chrom_hi[chrom_id[i]], hi);
+        for (int s = kMinShift; s <= kMaxShift; ++s) entries_at[s] += (uint64_t)((hi >> s) - (lo >> s) + 1);
+    }
+    auto bins_at = [&](int s) {
+        uint64_t b = 0;
+        for (uint32_t c = 0; c < n_chrom; ++c)
+            if (chrom_hi[c] >= 0) b += (uint64_t)(chrom_hi[c] >> s) + 1;
+        return b;
+    };
+    int shift = bin_shift;
+    if (shift == 0) {
+        // smallest bins whose replication stays moderate and whose offset table stays small
+        shift = kMaxShift;
+        for (int s = 9; s <= kMaxShift; ++s) {
+            if (entries_at[s] <= hittable + hittable * 3 / 4 + 1024 && bins_at(s) <= (48ull << 20)) {
+                shift = s;
+                break;
+            }
+        }
+    }
+    const uint64_t n_entries = entries_at[shift];
+    const uint64_t n_bins = bins_at(shift);
+    if (n_entries >= 0xFFFFFFF0ull || n_bins >= 0xFFFFFFF0ull)
+        return tec_fail(ctx, TEC_EOVERFLOW, "tec_index_build: %llu entries / %llu bins exceed 32-bit offsets",
+                        (unsigned long long)n_entries, (unsigned long long)n_bins);
+
+    std::vector<uint32_t> chrom_base(n_chrom, 0), chrom_nbins(n_chrom, 0);
+    {
+        uint64_t b = 0;
+        for (uint32_t c = 0; c < n_chrom; ++c) {
+            chrom_base[c] = (uint32_t)b;
+            chrom_nbins[c] = chrom_hi[c] >= 0 ? (uint32_t)((chrom_hi[c] >> shift) + 1) : 0;
+            b += chrom_nbins[c];
+        }
+    }
+
+    // pass 2: counting sort of (feature, fine bin) pairs
+    std::vector<uint32_t> bin_off(n_bins + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        int64_t lo, hi;
+        if (!coverage(left[i], right[i], &lo, &hi)) continue;
+        const uint32_t base = chrom_base[chrom_id[i]];
+        for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) ++bin_off[base + b + 1];
+    }
+    for (uint64_t b = 0; b < n_bins; ++b) bin_off[b + 1] += bin_off[b];
+    std::vector<tec_entry> entries(n_entries);
+    {
+        std::vector<uint32_t> cursor(bin_off.begin(), bin_off.end() - 1);
+        for (uint64_t i = 0; i < n; ++i) {
+            int64_t lo, hi;
+            if (!coverage(left[i], right[i], &lo, &hi)) continue;
+            const uint32_t base = chrom_base[chrom_id[i]];
+            const tec_entry e{left[i], right[i], meta[i], 0u};
+            for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) entries[cursor[base + b]++] = e;
+        }
+    }
+    const uint32_t name_mask = (1u << TEC_META_NAME_BITS) - 1;
+    for (uint64_t b = 0; b < n_bins; ++b) {
+        const uint32_t a = bin_off[b], z = bin_off[b + 1];
+        if (z - a > 1)
+            std::sort(entries.begin() + a, entries.begin() + z, [&](const tec_entry& x, const tec_entry& y) {
+                const uint32_t nx = x.meta & name_mask, ny = y.meta & name_mask;
+                if (nx != ny) return nx < ny;
+                if (x.left != y.left) return x.left < y.left;
+                if (x.right != y.right) return x.right < y.right;
+                return x.meta < y.meta;
+            });
+    }
+
+    // upload as one blob
+    TEC_HIP(ctx, hipSetDevice(ctx->device));
+    TEC_HIP(ctx, hipDeviceSynchronize());
+    const size_t o_off = 0;
+    const size_t o_ent = align_up(o_off + (n_bins + 1) * sizeof(uint32_t), 256);
+    const size_t o_cb = align_up(o_ent + std::max<uint64_t>(n_entries, 1) * sizeof(tec_entry), 256);
+    const size_t o_cn = align_up(o_cb + n_chrom * sizeof(uint32_t), 256);
+    const size_t total = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
+    void* blob = nullptr;
+    TEC_HIP(ctx, hipMalloc(&blob, total));
+    char* p = static_cast<char*>(blob);
+    hipError_t e = hipMemcpy(p + o_off, bin_off.data(), (n_bins + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_entries) e = hipMemcpy(p + o_ent, entries.data(), n_entries * sizeof(tec_entry), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p + o_cb, chrom_base.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p + o_cn, chrom_nbins.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
+    unsigned long long* counts = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&counts, (size_t)n_names * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(counts, 0, (size_t)n_names * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        if (counts) (void)hipFree(counts);
+        return tec_fail(ctx, TEC_EHIP, "tec_index_build: upload failed: %s", hipGetErrorString(e));
+    }
+    if (ctx->d_index_blob) (void)hipFree(ctx->d_index_blob);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    ctx->d_index_blob = blob;
+    ctx->d_counts = counts;
+    ctx->idx.bin_off = reinterpret_cast<const uint32_t*>(p + o_off);
+    ctx->idx.entries = reinterpret_cast<const tec_entry*>(p + o_ent);
+    ctx->idx.chrom_base = reinterpret_cast<const uint32_t*>(p + o_cb);
+    ctx->idx.chrom_nbins = reinterpret_cast<const uint32_t*>(p + o_cn);
+    ctx->idx.n_chrom = n_chrom;
+    ctx->idx.n_names = n_names;
+    ctx->idx.shift = shift;
+    ctx->idx.class_mask = class_mask;
+    ctx->n_entries = n_entries;
+    ctx->n_bins = n_bins;
+    ctx->index_bytes = total;
+    ctx->have_index = true;
+    return TEC_OK;
+}
+
+extern "C" int tec_index_info(const tec_ctx* ctx, uint64_t* n_entries, uint64_t* n_bins, int* bin_shift,
+                              uint64_t* device_bytes) {
+    if (!ctx || !ctx->have_index) return TEC_ESTATE;
+    if (n_entries) *n_entries = ctx->n_entries;
+    if (n_bins) *n_bins = ctx->n_bins;
+    if (bin_shift) *bin_shift = ctx->idx.shift;
+    if (device_bytes) *device_bytes = ctx->index_bytes;
+    return TEC_OK;
+}

@@ -1,0 +1,85 @@
+// Internal declarations shared by the translation units of libtecount.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/tecount.h"
+
+// One fine-bin entry: 16 bytes so that a lane fetches it with a single global_load_dwordx4.
+struct tec_entry {
+    int32_t left;
+    int32_t right;
+    uint32_t meta;  // name id | class << 26 | strand << 29
+    uint32_t pad;
+};
+static_assert(sizeof(tec_entry) == 16, "entry must be one dwordx4");
+
+// Device view of the resident index.
+struct tec_index_dev {
+    const uint32_t* bin_off;      // [n_bins + 1] CSR offsets into entries, all chromosomes concatenated
+    const tec_entry* entries;     // [n_entries], sorted by name id inside each fine bin
+    const uint32_t* chrom_base;   // [n_chrom] first fine bin of each chromosome
+    const uint32_t* chrom_nbins;  // [n_chrom] number of fine bins of each chromosome
+    uint32_t n_chrom;
+    uint32_t n_names;
+    int shift;
+    uint32_t class_mask;          // OR over features of (1 << class)
+};
+
+struct tec_event_pair {
+    hipEvent_t start, stop;
+};
+
+struct tec_slot {  // one staged batch in HBM
+    void* d_buf = nullptr;
+    size_t cap = 0;
+    hipEvent_t copied = nullptr;    // H2D of this slot finished (host buffers reusable)
+    hipEvent_t consumed = nullptr;  // kernel reading this slot finished (slot reusable)
+    uint64_t ticket = 0;
+};
+
+struct tec_ctx {
+    int device = 0;
+    std::string err;
+    hipStream_t s_copy = nullptr;
+    hipStream_t s_compute = nullptr;
+
+    // index
+    bool have_index = false;
+    tec_index_dev idx{};
+    void* d_index_blob = nullptr;
+    uint64_t n_entries = 0, n_bins = 0, index_bytes = 0;
+
+    // bulk state
+    bool bulk_open = false;
+    int mapq_min = 20;
+    unsigned long long* d_counts = nullptr;  // [n_names]
+    unsigned long long* d_stats = nullptr;   // [8]: units, assigned, lowq, badchrom, qcfail, enhancer_flag
+    static constexpr int kSlots = 3;
+    tec_slot slots[kSlots];
+    uint64_t next_ticket = 1;
+    std::vector<tec_event_pair> ev_pool;
+    size_t ev_used = 0;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    int n_cu = 256;
+};
+
+int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
+
+#define TEC_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return tec_fail((ctx), TEC_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                                \
+    } while (0)
+
+// bulk.hip
+int tec_bulk_release(tec_ctx* ctx);

@@ -1,0 +1,148 @@
+"""Alignment records as structure-of-arrays batches, and their reduction to counting units.
+
+This is the boundary the reference crosses with `next(sam)` on a pysam.AlignmentFile
+(te_count/te_count.py:65,78-79 / 190,203 / 351,393): every source below yields RecordBatch
+objects carrying exactly the per-record fields the reference reads (te_count.py:81-98,
+204-214, 394-438).
+"""
+
+import numpy as np
+
+from .index import read_chrom_key
+
+FLAG_FILTER = 0x4 | 0x200 | 0x400
+
+
+class RecordBatch:
+    """tid/pos/end/flag/mapq arrays (+ optional qname list, cb/ub object arrays for --sc)."""
+    __slots__ = ('tid', 'pos', 'end', 'flag', 'mapq', 'qname', 'cb', 'ub')
+
+    def __init__(self, tid, pos, end, flag, mapq, qname=None, cb=None, ub=None):
+        self.tid = np.ascontiguousarray(tid, np.int32)
+        self.pos = np.ascontiguousarray(pos, np.int32)
+        self.end = np.ascontiguousarray(end, np.int32)
+        self.flag = np.ascontiguousarray(flag, np.uint16)
+        self.mapq = np.ascontiguousarray(mapq, np.uint8)
+        self.qname = qname
+        self.cb = cb
+        self.ub = ub
+
+    def __len__(self):
+        return len(self.tid)
+
+
+class ListSource:
+    """In-memory source over record dicts (schema: oracle/ref_harness.py); used by tests and as
+    the adapter for any pysam-like iterator."""
+
+    def __init__(self, records, batch_size=1 << 20):
+        self.records = records
+        self.batch_size = batch_size
+        names = []
+        seen = {}
+        for r in records:
+            n = r.get('rname')
+            if n is not None and n not in seen:
+                seen[n] = len(names)
+                names.append(n)
+        self.reference_names = names
+        self._tid = seen
+
+    def batches(self, want_tags=False):
+        recs = self.records
+        for a in range(0, len(recs), self.batch_size):
+            chunk = recs[a:a + self.batch_size]
+            tid = [self._tid.get(r.get('rname'), -1) for r in chunk]
+            cb = ub = None
+            if want_tags:
+                cb = [_first_tag(r, 'CB', 'CR') for r in chunk]
+                ub = [_first_tag(r, 'UB', 'UR') for r in chunk]
+            yield RecordBatch(tid, [r['pos'] for r in chunk], [r['end'] for r in chunk],
+                              [r['flag'] for r in chunk], [r['mapq'] for r in chunk],
+                              qname=[r.get('qname', 'q') for r in chunk], cb=cb, ub=ub)
+
+    def close(self):
+        pass
+
+
+def _first_tag(r, a, b):
+    t = r.get('tags', {})
+    if a in t:
+        return t[a]
+    return t.get(b)
+
+
+def _mate_key(q):
+    return '_'.join(q.split('/')[0:-1])  # te_count.py:92
+
+
+def se_units(batch, tid_map):
+    """SE unit = one record: chrom, p1 = reference_start, p2 = reference_end (te_count.py:212-214)."""
+    chrom = np.where(batch.tid >= 0, tid_map[np.clip(batch.tid, 0, max(0, len(tid_map) - 1))], -1).astype(np.int32) \
+        if len(tid_map) else np.full(len(batch), -1, np.int32)
+    return chrom, batch.pos, batch.end, batch.flag, batch.mapq
+
+
+class PairAssembler:
+    """PE unit = records (2k, 2k+1) of the file (te_count.py:78-79): chrom and mapq of read 1,
+    p1/p2 = the two reference_starts (te_count.py:96-98), flags OR-ed for the 0x4/0x200/0x400
+    filter (te_count.py:81-86).  Carries an odd record across batch boundaries; a trailing
+    unpaired record is dropped, as `next(sam)` raising StopIteration does in the reference."""
+
+    def __init__(self, tid_map, quality_threshold):
+        self.tid_map = tid_map
+        self.q = quality_threshold
+        self._carry = None  # (tid, pos, flag, mapq, qname)
+
+    def units(self, batch):
+        tid, pos, flag, mapq = batch.tid, batch.pos, batch.flag, batch.mapq
+        qn = batch.qname
+        if self._carry is not None:
+            c = self._carry
+            tid = np.concatenate([[c[0]], tid]).astype(np.int32)
+            pos = np.concatenate([[c[1]], pos]).astype(np.int32)
+            flag = np.concatenate([[c[2]], flag]).astype(np.uint16)
+            mapq = np.concatenate([[c[3]], mapq]).astype(np.uint8)
+            if qn is not None:
+                qn = [c[4]] + list(qn)
+            self._carry = None
+        n = len(tid)
+        if n % 2:
+            self._carry = (tid[-1], pos[-1], flag[-1], mapq[-1], qn[-1] if qn is not None else None)
+            n -= 1
+        t1, p1, p2 = tid[0:n:2], pos[0:n:2], pos[1:n:2]
+        fl = (flag[0:n:2] | flag[1:n:2]).astype(np.uint16)
+        mq = mapq[0:n:2]
+        if qn is not None:
+            self._check_names(qn, n, fl, mq)
+        tm = self.tid_map
+        chrom = np.where(t1 >= 0, tm[np.clip(t1, 0, max(0, len(tm) - 1))], -1).astype(np.int32) \
+            if len(tm) else np.full(n // 2, -1, np.int32)
+        return chrom, np.ascontiguousarray(p1), np.ascontiguousarray(p2), fl, np.ascontiguousarray(mq)
+
+    def _check_names(self, qn, n, fl, mq):
+        # The reference compares mate names only for pairs that passed the flag and mapq filters
+        # (te_count.py:81-94) and dies on a mismatch (sys.quit does not exist -> AttributeError).
+        if not any('/' in q for q in qn[:n]):
+            return  # names without '/' always compare '' == ''
+        live = ((fl & FLAG_FILTER) == 0) & (mq.astype(np.int64) >= self.q)
+        for k in np.nonzero(live)[0]:
+            if _mate_key(qn[2 * k]) != _mate_key(qn[2 * k + 1]):
+                raise AttributeError("module 'sys' has no attribute 'quit'")
+
+
+def chrom_class_table(reference_names):
+    """--sc: per tid, (skip, class id).  skip = '_' or 'alt' in the read-side chromosome string
+    (te_count.py:431-433); the class id is that string's identity (two header names that
+    reduce to the same string are the same class)."""
+    keys, lookup = [], {}
+    skip = np.zeros(len(reference_names), bool)
+    cls = np.zeros(len(reference_names), np.int32)
+    for i, n in enumerate(reference_names):
+        k = read_chrom_key(n)
+        skip[i] = ('_' in k) or ('alt' in k)
+        if k not in lookup:
+            lookup[k] = len(keys)
+            keys.append(k)
+        cls[i] = lookup[k]
+    return skip, cls, keys

@@ -1,0 +1,94 @@
+"""CPU-only checks: the C oracle against the golden vectors (through the product's host-side
+index/unit code), the index file format, and the C ABI's symbol table."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, load_golden
+from helpers import flat_from_golden, units_from_records
+from oracle import c_oracle
+from oracle import te_oracle as orc
+from te_counter_amd import _lib
+from te_counter_amd.index import FlatIndex, index_chrom_key
+
+BULK = [n for n in golden_names('bulk_') if '_err_' not in n]
+
+
+@pytest.mark.parametrize('name', BULK)
+def test_c_oracle_golden(name):
+    g = load_golden(name)
+    flat = flat_from_golden(g)
+    units, nrec = units_from_records(flat, g['records'], g['params']['paired'], g['params']['q'],
+                                     batch_size=7 if 'quirks' in name else 1000)
+    ci = c_oracle.COracleIndex.from_flat(flat)
+    counts, stats = ci.bulk_count(*units, g['params']['q'])
+    got = {n: int(c) for n, c in zip(flat.names, counts)}
+    assert got == g['expected']['result']
+    total = (nrec // 2 if g['params']['paired'] else nrec) + 1
+    assert total == g['expected']['total_reads']
+    assert orc.format_bulk_tsv(got, total) == g['expected']['tsv']
+    # stats agree with the Python oracle
+    _, _, st = orc.bulk_count(g['features'], g['records'], g['params']['paired'], g['params']['q'])
+    assert stats == st
+
+
+def test_c_oracle_enhancer_crash():
+    g = load_golden('bulk_err_enhancer')
+    flat = flat_from_golden(g)
+    units, _ = units_from_records(flat, g['records'], False)
+    with pytest.raises(NameError):
+        c_oracle.COracleIndex.from_flat(flat).bulk_count(*units, 20)
+
+
+def test_pe_carry_across_batches():
+    g = load_golden('bulk_pe_rand11')
+    flat = flat_from_golden(g)
+    a, _ = units_from_records(flat, g['records'], True, batch_size=1 << 20)
+    for bs in (1, 3, 7, 1001):
+        b, _ = units_from_records(flat, g['records'], True, batch_size=bs)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_pe_name_mismatch_raises():
+    g = load_golden('bulk_err_pe_mismatch')
+    flat = flat_from_golden(g)
+    with pytest.raises(AttributeError):
+        units_from_records(flat, g['records'], True)
+
+
+def test_chrom_keys():
+    assert index_chrom_key('chr1') == '1' and index_chrom_key('chrX') == 'X'
+    assert index_chrom_key('chr1_KI270706v1_random') == '1_KI270706V1_RANDOM'
+    assert index_chrom_key('chrUn_GL000220') == 'UN_GL000220'
+    flat = FlatIndex.from_features([{'chr': 'chrM', 'left': 1, 'right': 5, 'name': 'a', 'type': 'TE', 'ensg': 'a', 'strand': '+'},
+                                    {'chr': 'chrUn_x', 'left': 1, 'right': 5, 'name': 'b', 'type': 'TE', 'ensg': 'b', 'strand': '-'}])
+    assert flat.chrom_id_of_read('chrM') == 0 and flat.chrom_id_of_read('M') == 0
+    assert flat.chrom_id_of_read('chrMT') == -1 and flat.chrom_id_of_read('chrm') == -1
+    assert flat.chrom_id_of_read('chrUn_x') == -1  # index key is upper-cased, the read side is not
+    assert flat.chrom_id_of_read('chrUN_X') == 1
+
+
+def test_index_file_roundtrip(tmp_path):
+    g = load_golden('bulk_se_rand11')
+    flat = flat_from_golden(g)
+    p = str(tmp_path / 'x.tecidx')
+    flat.save(p)
+    back = FlatIndex.load(p)
+    assert back.names == flat.names and back.chrom_keys == flat.chrom_keys and back.strands == flat.strands
+    for k in ('chrom_id', 'left', 'right', 'meta'):
+        assert np.array_equal(getattr(back, k), getattr(flat, k))
+    assert back.names == orc.feature_names(g['features'])
+
+
+def test_cabi_exports_every_declared_symbol():
+    """libtecount.so loads on a GPU-less box and exports exactly what include/tecount.h declares."""
+    hdr = open(os.path.join(ROOT, 'include', 'tecount.h')).read()
+    declared = sorted(set(re.findall(r'\b(tec_[a-z_]+)\s*\(', hdr)))
+    assert declared == _lib.exported_symbols()
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tec_version() == 100
