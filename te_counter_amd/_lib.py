@@ -62,6 +62,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.environ.get('TEC_NO_TORCH'):
+        # torch wheels ship their own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+        # process cannot both own the GPU.  Importing torch first makes the loader resolve our
+        # DT_NEEDED libamdhip64.so.7 to the copy torch has already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s is missing: build it with `make` (or __graft_entry__.build()); '
                           'te_counter_amd has no CPU fallback' % LIB_PATH)
