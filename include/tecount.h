@@ -133,7 +133,7 @@ int tec_bulk_submit_device(tec_ctx* ctx, uint64_t n_units, const int32_t* d_chro
 /* Wait for everything submitted so far. */
 int tec_bulk_sync(tec_ctx* ctx);
 
-/* Device address of the running uint64 count vector (n_names entries, index = name id) and of
+/* Device address of the running uint64 count vector (n_names entries, in the library's INTERNAL name order, identical on every GPU that holds the same index; tec_bulk_finish maps it back to name ids) and of
  * the 5-word stats block {units, assigned, lowq, badchrom, qcfail}; for the caller's multi-GPU
  * sum-reduce (RCCL through torch.distributed).  Valid until tec_destroy / the next
  * tec_index_build. */

@@ -23,7 +23,9 @@ namespace {
 constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
 constexpr uint32_t kCountable = (1u << TEC_CLASS_GENE) | (1u << TEC_CLASS_TE) | (1u << TEC_CLASS_SNRNA);
 constexpr uint32_t kNoName = 0xFFFFFFFFu;
-constexpr int kBlock = 256;
+constexpr int kBlock = 1024;
+constexpr uint32_t kChunk = 4096;           // units per workgroup per grid-stride step
+constexpr uint32_t kLdsBytes = 79 * 1024;   // per workgroup: two workgroups fit a CU's 160 KiB
 
 __device__ __forceinline__ int floordiv_bs(long long x) {
     long long q = x / TEC_BUCKET_SIZE;
@@ -54,21 +56,37 @@ __device__ __forceinline__ void bin_range(const tec_index_dev& idx, int chrom, i
     *z = idx.bin_off[g + 1];
 }
 
+// Where a hit is counted.  The k_lds hottest names (internal ids are ordered by expected hit
+// rate, see index.hip) live in a per-workgroup LDS histogram of packed 16-bit counters
+// (ds_add_u32 of 1 << 16*(id&1)); a workgroup flushes it to the 64-bit global vector before any
+// counter can reach 65536.  Colder names go straight to global 64-bit atomics.
+struct Sink {
+    uint32_t* lds;
+    uint32_t k_lds;
+    unsigned long long* counts;
+    __device__ __forceinline__ void add(uint32_t name) const {
+        if (name < k_lds)
+            atomicAdd(&lds[name >> 1], 1u << ((name & 1u) * 16u));
+        else
+            atomicAdd(&counts[name], 1ull);
+    }
+};
+
 // Walks the hits of one unit.  COUNT: add 1 to every distinct hit name.  Returns the OR of
 // (1 << class) over all hits (0 = no hit).
 template <bool COUNT>
 __device__ __forceinline__ uint32_t walk_hits(const tec_index_dev& idx, const Unit& u, uint32_t a0, uint32_t a1,
-                                              uint32_t b0, uint32_t b1, unsigned long long* counts) {
+                                              uint32_t b0, uint32_t b1, const Sink& sink) {
     uint32_t classes = 0;
     const tec_entry* __restrict__ ent = idx.entries;
-    if (a0 == b0) {  // both edges fall into one fine bin (or both ranges are empty)
+    if (a0 == b0) {  // both edges fall into one fine bin
         uint32_t last = kNoName;
         for (uint32_t j = a0; j < a1; ++j) {
             const tec_entry e = ent[j];
             if ((test1(e, u) || test2(e, u)) && is_candidate(e, u)) {
                 classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
                 const uint32_t name = e.meta & kNameMask;
-                if (COUNT && name != last) atomicAdd(&counts[name], 1ull);
+                if (COUNT && name != last) sink.add(name);
                 last = name;
             }
         }
@@ -80,7 +98,7 @@ __device__ __forceinline__ uint32_t walk_hits(const tec_index_dev& idx, const Un
         if (test1(e, u) && is_candidate(e, u)) {
             classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
             const uint32_t name = e.meta & kNameMask;
-            if (COUNT && name != last) atomicAdd(&counts[name], 1ull);
+            if (COUNT && name != last) sink.add(name);
             last = name;
         }
     }
@@ -96,7 +114,7 @@ __device__ __forceinline__ uint32_t walk_hits(const tec_index_dev& idx, const Un
                     const tec_entry f = ent[k];
                     seen = (f.meta & kNameMask) == name && test1(f, u) && is_candidate(f, u);
                 }
-                if (!seen) atomicAdd(&counts[name], 1ull);
+                if (!seen) sink.add(name);
             }
             last = name;
         }
@@ -109,60 +127,89 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
+__device__ __forceinline__ void flush_hist(uint32_t* hist, uint32_t words, unsigned long long* counts) {
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) {
+        const uint32_t v = hist[w];
+        if (v) {
+            hist[w] = 0;
+            if (v & 0xFFFFu) atomicAdd(&counts[2 * w], (unsigned long long)(v & 0xFFFFu));
+            if (v >> 16) atomicAdd(&counts[2 * w + 1], (unsigned long long)(v >> 16));
+        }
+    }
+    __syncthreads();
+}
+
 // MIXED = the index holds classes that are not countable in bulk (miRNA..., enhancer): the class
 // decision then needs a first pass over the hits before anything may be counted.
+// Persistent workgroups walk the batch in chunks of `chunk` units (grid-stride over chunks).
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
                                                            const int32_t* __restrict__ p1,
                                                            const int32_t* __restrict__ p2,
                                                            const uint16_t* __restrict__ flag,
                                                            const uint8_t* __restrict__ mapq, uint64_t n, int mapq_min,
-                                                           unsigned long long* counts, unsigned long long* stats) {
+                                                           unsigned long long* counts, unsigned long long* stats,
+                                                           uint32_t k_lds, uint32_t chunk) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t words = (k_lds + 1u) >> 1;
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
+    __syncthreads();
+    const Sink sink{hist, k_lds, counts};
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const unsigned fl = flag[i];
-        if (fl & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
-            ++n_qc;
-            continue;
+    uint32_t since_flush = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
+        if (since_flush + chunk > 65535u) {  // a 16-bit counter gains at most 1 per unit
+            flush_hist(hist, words, counts);
+            since_flush = 0;
         }
-        if ((int)mapq[i] < mapq_min) {
-            ++n_lowq;
-            continue;
-        }
-        const int c = chrom[i];
-        if (c < 0 || (uint32_t)c >= idx.n_chrom) {
-            ++n_bad;
-            continue;
-        }
-        Unit u;
-        u.p1 = p1[i];
-        u.p2 = p2[i];
-        u.b1 = floordiv_bs((long long)u.p1 - 1);
-        u.b2 = floordiv_bs((long long)u.p2 + 1);
-        uint32_t a0, a1, b0, b1;
-        bin_range(idx, c, u.p1, &a0, &a1);
-        bin_range(idx, c, u.p2, &b0, &b1);
-        if (a0 == a1 && b0 == b1) continue;
-        if (a0 == a1) {  // only the second edge has a list: let it run as the "first" one
-            a0 = b0;
-            a1 = b1;
-        } else if (b0 == b1) {
-            b0 = a0;
-            b1 = a1;
-        }
-        if (MIXED) {
-            const uint32_t classes = walk_hits<false>(idx, u, a0, a1, b0, b1, counts);
-            if (classes == 0) continue;
-            ++n_assigned;
-            if (classes & kCountable)
-                walk_hits<true>(idx, u, a0, a1, b0, b1, counts);
-            else if (classes & (1u << TEC_CLASS_ENHANCER))
-                ++n_enh;
-        } else {
-            if (walk_hits<true>(idx, u, a0, a1, b0, b1, counts)) ++n_assigned;
+        since_flush += chunk;
+        const uint64_t end = base + chunk < n ? base + chunk : n;
+        for (uint64_t i = base + threadIdx.x; i < end; i += kBlock) {
+            const unsigned fl = flag[i];
+            if (fl & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
+                ++n_qc;
+                continue;
+            }
+            if ((int)mapq[i] < mapq_min) {
+                ++n_lowq;
+                continue;
+            }
+            const int c = chrom[i];
+            if (c < 0 || (uint32_t)c >= idx.n_chrom) {
+                ++n_bad;
+                continue;
+            }
+            Unit u;
+            u.p1 = p1[i];
+            u.p2 = p2[i];
+            u.b1 = floordiv_bs((long long)u.p1 - 1);
+            u.b2 = floordiv_bs((long long)u.p2 + 1);
+            uint32_t a0, a1, b0, b1;
+            bin_range(idx, c, u.p1, &a0, &a1);
+            bin_range(idx, c, u.p2, &b0, &b1);
+            if (a0 == a1 && b0 == b1) continue;
+            if (a0 == a1) {  // only the second edge has a list: let it run as the "first" one
+                a0 = b0;
+                a1 = b1;
+            } else if (b0 == b1) {
+                b0 = a0;
+                b1 = a1;
+            }
+            if (MIXED) {
+                const uint32_t classes = walk_hits<false>(idx, u, a0, a1, b0, b1, sink);
+                if (classes == 0) continue;
+                ++n_assigned;
+                if (classes & kCountable)
+                    walk_hits<true>(idx, u, a0, a1, b0, b1, sink);
+                else if (classes & (1u << TEC_CLASS_ENHANCER))
+                    ++n_enh;
+            } else {
+                if (walk_hits<true>(idx, u, a0, a1, b0, b1, sink)) ++n_assigned;
+            }
         }
     }
+    flush_hist(hist, words, counts);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     n_assigned = wave_sum(n_assigned);
     n_lowq = wave_sum(n_lowq);
@@ -226,16 +273,18 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
         }
     }
     tec_event_pair& ev = ctx->ev_pool[ctx->ev_used++];
-    const uint64_t want = (n + kBlock - 1) / kBlock;
-    const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * 8);
+    const uint64_t want = (n + kChunk - 1) / kChunk;
+    const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * 2);
     const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0;
+    const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, kLdsBytes / 2);
+    const size_t lds = (size_t)((k_lds + 1) / 2) * 4;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
     if (mixed)
-        hipLaunchKernelGGL(count_bulk_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->s_compute, ctx->idx, u.chrom, u.p1,
-                           u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats);
+        hipLaunchKernelGGL(count_bulk_kernel<true>, dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom,
+                           u.p1, u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, kChunk);
     else
-        hipLaunchKernelGGL(count_bulk_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->s_compute, ctx->idx, u.chrom, u.p1,
-                           u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats);
+        hipLaunchKernelGGL(count_bulk_kernel<false>, dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom,
+                           u.p1, u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, kChunk);
     TEC_HIP(ctx, hipGetLastError());
     TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
     ++ctx->kernel_launches;
@@ -243,6 +292,15 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
 }
 
 }  // namespace
+
+int tec_bulk_init(tec_ctx* ctx) {
+    // 79 KiB of dynamic LDS per workgroup needs the opt-in above the 64 KiB default
+    TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&count_bulk_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&count_bulk_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    return TEC_OK;
+}
 
 int tec_bulk_release(tec_ctx* ctx) {
     for (auto& s : ctx->slots) {
@@ -365,8 +423,11 @@ extern "C" int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats)
     if (rc) return rc;
     unsigned long long h[8];
     TEC_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
-    if (counts)
-        TEC_HIP(ctx, hipMemcpy(counts, ctx->d_counts, (size_t)ctx->idx.n_names * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (counts) {  // device vector is in internal (hotness) order
+        std::vector<uint64_t> tmp(ctx->idx.n_names);
+        TEC_HIP(ctx, hipMemcpy(tmp.data(), ctx->d_counts, tmp.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < ctx->idx.n_names; ++i) counts[ctx->int2ext[i]] = tmp[i];
+    }
     if (stats) {
         stats->units = h[0];
         stats->assigned = h[1];

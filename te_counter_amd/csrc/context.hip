@@ -44,6 +44,11 @@ extern "C" int tec_create(int device_id, tec_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipMalloc(&ctx->d_stats, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(stats)");
     if ((e = hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(stats)");
+    if (tec_bulk_init(ctx) != TEC_OK) {
+        g_create_err = ctx->err;
+        tec_destroy(ctx);
+        return TEC_EHIP;
+    }
     *out = ctx;
     return TEC_OK;
 }

@@ -52,6 +52,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     uint64_t entries_at[kMaxShift + 1] = {0};
     uint64_t hittable = 0;
     uint32_t class_mask = 0;
+    std::vector<uint64_t> weight(n_names, 0);  // bp covered per name ~ expected hit rate
     for (uint64_t i = 0; i < n; ++i) {
         if (chrom_id[i] < 0 || (uint32_t)chrom_id[i] >= n_chrom)
             return tec_fail(ctx, TEC_EINVAL, "tec_index_build: feature %llu has chrom id %d", (unsigned long long)i, chrom_id[i]);
@@ -62,6 +63,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
         int64_t lo, hi;
         if (!coverage(left[i], right[i], &lo, &hi)) continue;
         ++hittable;
+        weight[meta[i] & ((1u << TEC_META_NAME_BITS) - 1)] += (uint64_t)(hi - lo);
         chrom_hi[chrom_id[i]] = std::max(chrom_hi[chrom_id[i]], hi);
         for (int s = kMinShift; s <= kMaxShift; ++s) entries_at[s] += (uint64_t)((hi >> s) - (lo >> s) + 1);
     }
@@ -98,6 +100,14 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
         }
     }
 
+    // Internal name ids: hottest first, so that the names the kernel keeps in its LDS histogram
+    // (ids < k_lds, bulk.hip) are the ones that would otherwise serialise on global atomics.
+    std::vector<uint32_t> int2ext(n_names), ext2int(n_names);
+    for (uint32_t i = 0; i < n_names; ++i) int2ext[i] = i;
+    std::stable_sort(int2ext.begin(), int2ext.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    for (uint32_t i = 0; i < n_names; ++i) ext2int[int2ext[i]] = i;
+    const uint32_t name_mask = (1u << TEC_META_NAME_BITS) - 1;
+
     // pass 2: counting sort of (feature, fine bin) pairs
     std::vector<uint32_t> bin_off(n_bins + 1, 0);
     for (uint64_t i = 0; i < n; ++i) {
@@ -114,11 +124,10 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
             int64_t lo, hi;
             if (!coverage(left[i], right[i], &lo, &hi)) continue;
             const uint32_t base = chrom_base[chrom_id[i]];
-            const tec_entry e{left[i], right[i], meta[i], 0u};
+            const tec_entry e{left[i], right[i], (meta[i] & ~name_mask) | ext2int[meta[i] & name_mask], 0u};
             for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) entries[cursor[base + b]++] = e;
         }
     }
-    const uint32_t name_mask = (1u << TEC_META_NAME_BITS) - 1;
     for (uint64_t b = 0; b < n_bins; ++b) {
         const uint32_t a = bin_off[b], z = bin_off[b + 1];
         if (z - a > 1)
@@ -166,6 +175,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     ctx->idx.n_names = n_names;
     ctx->idx.shift = shift;
     ctx->idx.class_mask = class_mask;
+    ctx->int2ext.swap(int2ext);
     ctx->n_entries = n_entries;
     ctx->n_bins = n_bins;
     ctx->index_bytes = total;

@@ -55,6 +55,7 @@ struct tec_ctx {
     tec_index_dev idx{};
     void* d_index_blob = nullptr;
     uint64_t n_entries = 0, n_bins = 0, index_bytes = 0;
+    std::vector<uint32_t> int2ext;  // internal (hotness-ordered) name id -> caller's name id
 
     // bulk state
     bool bulk_open = false;
@@ -82,4 +83,5 @@ int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 // bulk.hip
+int tec_bulk_init(tec_ctx* ctx);
 int tec_bulk_release(tec_ctx* ctx);
