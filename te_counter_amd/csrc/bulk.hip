@@ -15,6 +15,7 @@
 // duplicates inside one bin scan are adjacent, and a hit from the second edge's bin is checked
 // against the first bin by re-scanning it (both lists are short and L1-resident by then).
 #include <algorithm>
+#include <cstdlib>
 
 #include "tecount_internal.h"
 
@@ -24,37 +25,33 @@ constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
 constexpr uint32_t kCountable = (1u << TEC_CLASS_GENE) | (1u << TEC_CLASS_TE) | (1u << TEC_CLASS_SNRNA);
 constexpr uint32_t kNoName = 0xFFFFFFFFu;
 constexpr int kBlock = 1024;
-constexpr uint32_t kChunk = 4096;           // units per workgroup per grid-stride step
 constexpr uint32_t kLdsBytes = 79 * 1024;   // per workgroup: two workgroups fit a CU's 160 KiB
 
-__device__ __forceinline__ int floordiv_bs(long long x) {
-    long long q = x / TEC_BUCKET_SIZE;
-    if (x - q * TEC_BUCKET_SIZE < 0) --q;
-    return (int)q;
-}
+// floor(x / 10000) for x >= -1 (one 32-bit multiply-high; negative -> -1).
+__device__ __forceinline__ int bucket_of(int x) { return x < 0 ? -1 : (int)((unsigned)x / (unsigned)TEC_BUCKET_SIZE); }
 
 struct Unit {
-    int p1, p2;  // edge positions
-    int b1, b2;  // the two 10 kb buckets the reference would open
+    int p1, p2;     // edge positions
+    bool boundary;  // p1 or p2+1 is a multiple of 10000: the only case in which the reference's
+                    // bucket-candidate rule can reject a feature that passes an edge test
 };
 
+// Does the reference look at this feature at all?  It opens buckets b1 = floor((p1-1)/bs) and
+// b2 = floor((p2+1)/bs) only (te_count.py:106-116, 222-231); the feature is listed in buckets
+// floor(Gl/bs)..floor(Gr/bs) (genelist.py:371-378).  A feature that passes T1 contains p1 and
+// p1+1, so it is listed under floor(p1/bs), which equals b1 unless p1 % bs == 0; likewise for T2
+// and b2 unless (p2+1) % bs == 0.  Only then is the full test needed.
+__device__ __forceinline__ bool is_candidate_slow(const tec_entry& e, const Unit& u) {
+    const int lo = bucket_of(e.left), hi = bucket_of(e.right);
+    const int b1 = bucket_of(u.p1 < 0 ? -1 : u.p1 - 1);
+    const int b2 = bucket_of(u.p2 < -1 ? -1 : (u.p2 > 0x7FFFFFFE ? 0x7FFFFFFF : u.p2 + 1));
+    return (lo <= b1 && b1 <= hi) || (lo <= b2 && b2 <= hi);
+}
 __device__ __forceinline__ bool is_candidate(const tec_entry& e, const Unit& u) {
-    const int lo = e.left / TEC_BUCKET_SIZE;  // left >= 0 is enforced at build time
-    const int hi = floordiv_bs(e.right);
-    return (lo <= u.b1 && u.b1 <= hi) || (lo <= u.b2 && u.b2 <= hi);
+    return !u.boundary || is_candidate_slow(e, u);
 }
 __device__ __forceinline__ bool test1(const tec_entry& e, const Unit& u) { return u.p1 >= e.left && u.p1 < e.right; }
 __device__ __forceinline__ bool test2(const tec_entry& e, const Unit& u) { return u.p2 > e.left && u.p2 <= e.right; }
-
-__device__ __forceinline__ void bin_range(const tec_index_dev& idx, int chrom, int pos, uint32_t* a, uint32_t* z) {
-    *a = *z = 0;
-    if (pos < 0) return;
-    const uint32_t b = (uint32_t)pos >> idx.shift;
-    if (b >= idx.chrom_nbins[chrom]) return;
-    const uint32_t g = idx.chrom_base[chrom] + b;
-    *a = idx.bin_off[g];
-    *z = idx.bin_off[g + 1];
-}
 
 // Where a hit is counted.  The k_lds hottest names (internal ids are ordered by expected hit
 // rate, see index.hip) live in a per-workgroup LDS histogram of packed 16-bit counters
@@ -72,53 +69,47 @@ struct Sink {
     }
 };
 
-// Walks the hits of one unit.  COUNT: add 1 to every distinct hit name.  Returns the OR of
+// Walks the hits of one unit.  Lists [a0,a1) / [b0,b1) are non-empty; ea / eb are their
+// prefetched first entries.  COUNT: add 1 to every distinct hit name.  Returns the OR of
 // (1 << class) over all hits (0 = no hit).
 template <bool COUNT>
-__device__ __forceinline__ uint32_t walk_hits(const tec_index_dev& idx, const Unit& u, uint32_t a0, uint32_t a1,
-                                              uint32_t b0, uint32_t b1, const Sink& sink) {
+__device__ __forceinline__ uint32_t walk_hits(const tec_entry* __restrict__ ent, const Unit& u, uint32_t a0,
+                                              uint32_t a1, uint32_t b0, uint32_t b1, const tec_entry ea,
+                                              const tec_entry eb, const Sink& sink) {
     uint32_t classes = 0;
-    const tec_entry* __restrict__ ent = idx.entries;
-    if (a0 == b0) {  // both edges fall into one fine bin
-        uint32_t last = kNoName;
-        for (uint32_t j = a0; j < a1; ++j) {
-            const tec_entry e = ent[j];
-            if ((test1(e, u) || test2(e, u)) && is_candidate(e, u)) {
-                classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
-                const uint32_t name = e.meta & kNameMask;
-                if (COUNT && name != last) sink.add(name);
-                last = name;
-            }
-        }
-        return classes;
-    }
     uint32_t last = kNoName;
-    for (uint32_t j = a0; j < a1; ++j) {
-        const tec_entry e = ent[j];
-        if (test1(e, u) && is_candidate(e, u)) {
+    const bool one_bin = a0 == b0;  // both edges fall into one fine bin
+    auto first_edge = [&](const tec_entry e) {
+        if ((test1(e, u) || (one_bin && test2(e, u))) && is_candidate(e, u)) {
             classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
             const uint32_t name = e.meta & kNameMask;
             if (COUNT && name != last) sink.add(name);
             last = name;
         }
-    }
+    };
+    first_edge(ea);
+    for (uint32_t j = a0 + 1; j < a1; ++j) first_edge(ent[j]);
+    if (one_bin) return classes;
+
     last = kNoName;
-    for (uint32_t j = b0; j < b1; ++j) {
-        const tec_entry e = ent[j];
+    auto second_edge = [&](const tec_entry e) {
         if (test2(e, u) && is_candidate(e, u)) {
             classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
             const uint32_t name = e.meta & kNameMask;
             if (COUNT && name != last) {
-                bool seen = false;  // already counted through the first edge?
-                for (uint32_t k = a0; k < a1 && !seen; ++k) {
-                    const tec_entry f = ent[k];
-                    seen = (f.meta & kNameMask) == name && test1(f, u) && is_candidate(f, u);
-                }
+                // already counted through the first edge?  (both lists are short and cached)
+                auto same = [&](const tec_entry f) {
+                    return (f.meta & kNameMask) == name && test1(f, u) && is_candidate(f, u);
+                };
+                bool seen = same(ea);
+                for (uint32_t k = a0 + 1; k < a1 && !seen; ++k) seen = same(ent[k]);
                 if (!seen) sink.add(name);
             }
             last = name;
         }
-    }
+    };
+    second_edge(eb);
+    for (uint32_t j = b0 + 1; j < b1; ++j) second_edge(ent[j]);
     return classes;
 }
 
@@ -142,20 +133,28 @@ __device__ __forceinline__ void flush_hist(uint32_t* hist, uint32_t words, unsig
 
 // MIXED = the index holds classes that are not countable in bulk (miRNA..., enhancer): the class
 // decision then needs a first pass over the hits before anything may be counted.
-// Persistent workgroups walk the batch in chunks of `chunk` units (grid-stride over chunks).
-template <bool MIXED>
+// Persistent workgroups walk the batch in chunks of U * kBlock units (grid-stride over chunks).
+// Each lane carries U units through four stages so that the three dependent memory levels
+// (unit fields -> fine-bin offsets -> entries) of U units are in flight together:
+//   stage 1  coalesced loads of the unit SoA                       (5 x U loads per lane)
+//   stage 2  filters, fine-bin lookup: CSR offsets of both edges   (up to 4 x U gathers)
+//   stage 3  prefetch the first entry of each list                 (up to 2 x U 16-byte gathers)
+//   stage 4  walk the lists, count
+template <bool MIXED, int U>
 __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
                                                            const int32_t* __restrict__ p1,
                                                            const int32_t* __restrict__ p2,
                                                            const uint16_t* __restrict__ flag,
                                                            const uint8_t* __restrict__ mapq, uint64_t n, int mapq_min,
                                                            unsigned long long* counts, unsigned long long* stats,
-                                                           uint32_t k_lds, uint32_t chunk) {
+                                                           uint32_t k_lds) {
     extern __shared__ uint32_t hist[];
+    constexpr uint32_t chunk = U * kBlock;
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     __syncthreads();
     const Sink sink{hist, k_lds, counts};
+    const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     uint32_t since_flush = 0;
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
@@ -164,48 +163,90 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
             since_flush = 0;
         }
         since_flush += chunk;
-        const uint64_t end = base + chunk < n ? base + chunk : n;
-        for (uint64_t i = base + threadIdx.x; i < end; i += kBlock) {
-            const unsigned fl = flag[i];
-            if (fl & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
+
+        // ---- stage 1
+        unsigned fl[U], mq[U];
+        int ch[U];
+        Unit un[U];
+        bool live[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+            live[k] = i < n;
+            const uint64_t ii = live[k] ? i : 0;
+            // streamed once: non-temporal, so that the batch does not evict the index from L2 / MALL
+            fl[k] = __builtin_nontemporal_load(&flag[ii]);
+            mq[k] = __builtin_nontemporal_load(&mapq[ii]);
+            ch[k] = __builtin_nontemporal_load(&chrom[ii]);
+            un[k].p1 = __builtin_nontemporal_load(&p1[ii]);
+            un[k].p2 = __builtin_nontemporal_load(&p2[ii]);
+        }
+        // ---- stage 2
+        uint32_t a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            a0[k] = a1[k] = b0[k] = b1[k] = 0;
+            if (!live[k]) continue;
+            if (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
                 ++n_qc;
-                continue;
-            }
-            if ((int)mapq[i] < mapq_min) {
+                live[k] = false;
+            } else if ((int)mq[k] < mapq_min) {
                 ++n_lowq;
-                continue;
-            }
-            const int c = chrom[i];
-            if (c < 0 || (uint32_t)c >= idx.n_chrom) {
+                live[k] = false;
+            } else if (ch[k] < 0 || (uint32_t)ch[k] >= idx.n_chrom) {
                 ++n_bad;
+                live[k] = false;
+            } else {
+                const uint32_t nb = idx.chrom_nbins[ch[k]], cb = idx.chrom_base[ch[k]];
+                const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
+                if (un[k].p1 >= 0 && ba < nb) {
+                    a0[k] = idx.bin_off[cb + ba];
+                    a1[k] = idx.bin_off[cb + ba + 1];
+                }
+                if (un[k].p2 >= 0 && bb < nb) {
+                    b0[k] = idx.bin_off[cb + bb];
+                    b1[k] = idx.bin_off[cb + bb + 1];
+                }
+            }
+        }
+        // ---- stage 3
+        tec_entry ea[U], eb[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (!live[k]) continue;
+            if (a0[k] == a1[k] && b0[k] == b1[k]) {
+                live[k] = false;
                 continue;
             }
-            Unit u;
-            u.p1 = p1[i];
-            u.p2 = p2[i];
-            u.b1 = floordiv_bs((long long)u.p1 - 1);
-            u.b2 = floordiv_bs((long long)u.p2 + 1);
-            uint32_t a0, a1, b0, b1;
-            bin_range(idx, c, u.p1, &a0, &a1);
-            bin_range(idx, c, u.p2, &b0, &b1);
-            if (a0 == a1 && b0 == b1) continue;
-            if (a0 == a1) {  // only the second edge has a list: let it run as the "first" one
-                a0 = b0;
-                a1 = b1;
-            } else if (b0 == b1) {
-                b0 = a0;
-                b1 = a1;
+            if (a0[k] == a1[k]) {  // only the second edge has a list: let it run as the "first" one
+                a0[k] = b0[k];
+                a1[k] = b1[k];
+            } else if (b0[k] == b1[k]) {
+                b0[k] = a0[k];
+                b1[k] = a1[k];
             }
+            ea[k] = ent[a0[k]];
+            if (b0[k] != a0[k]) eb[k] = ent[b0[k]];
+            const unsigned q1 = (unsigned)un[k].p1 / (unsigned)TEC_BUCKET_SIZE;
+            const unsigned q2 = ((unsigned)un[k].p2 + 1u) / (unsigned)TEC_BUCKET_SIZE;
+            un[k].boundary = un[k].p1 < 0 || un[k].p2 < 0 || un[k].p2 == 0x7FFFFFFF ||
+                             (unsigned)un[k].p1 == q1 * TEC_BUCKET_SIZE ||
+                             (unsigned)un[k].p2 + 1u == q2 * TEC_BUCKET_SIZE;
+        }
+        // ---- stage 4
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (!live[k]) continue;
             if (MIXED) {
-                const uint32_t classes = walk_hits<false>(idx, u, a0, a1, b0, b1, sink);
+                const uint32_t classes = walk_hits<false>(ent, un[k], a0[k], a1[k], b0[k], b1[k], ea[k], eb[k], sink);
                 if (classes == 0) continue;
                 ++n_assigned;
                 if (classes & kCountable)
-                    walk_hits<true>(idx, u, a0, a1, b0, b1, sink);
+                    walk_hits<true>(ent, un[k], a0[k], a1[k], b0[k], b1[k], ea[k], eb[k], sink);
                 else if (classes & (1u << TEC_CLASS_ENHANCER))
                     ++n_enh;
             } else {
-                if (walk_hits<true>(idx, u, a0, a1, b0, b1, sink)) ++n_assigned;
+                if (walk_hits<true>(ent, un[k], a0[k], a1[k], b0[k], b1[k], ea[k], eb[k], sink)) ++n_assigned;
             }
         }
     }
@@ -222,6 +263,22 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
         if (n_bad) atomicAdd(&stats[3], (unsigned long long)n_bad);
         if (n_qc) atomicAdd(&stats[4], (unsigned long long)n_qc);
         if (n_enh) atomicAdd(&stats[5], (unsigned long long)n_enh);
+    }
+}
+
+typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
+                               const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t);
+
+template <int U>
+count_kernel_t pick_mixed(bool mixed) {
+    return mixed ? count_bulk_kernel<true, U> : count_bulk_kernel<false, U>;
+}
+count_kernel_t pick_kernel(bool mixed, int unroll) {
+    switch (unroll) {
+        case 1: return pick_mixed<1>(mixed);
+        case 8: return pick_mixed<8>(mixed);
+        case 4: return pick_mixed<4>(mixed);
+        default: return pick_mixed<2>(mixed);
     }
 }
 
@@ -273,18 +330,16 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
         }
     }
     tec_event_pair& ev = ctx->ev_pool[ctx->ev_used++];
-    const uint64_t want = (n + kChunk - 1) / kChunk;
+    const int unroll = ctx->unroll;
+    const uint64_t chunk = (uint64_t)unroll * kBlock;
+    const uint64_t want = (n + chunk - 1) / chunk;
     const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * 2);
     const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, kLdsBytes / 2);
     const size_t lds = (size_t)((k_lds + 1) / 2) * 4;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
-    if (mixed)
-        hipLaunchKernelGGL(count_bulk_kernel<true>, dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom,
-                           u.p1, u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, kChunk);
-    else
-        hipLaunchKernelGGL(count_bulk_kernel<false>, dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom,
-                           u.p1, u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, kChunk);
+    hipLaunchKernelGGL(pick_kernel(mixed, unroll), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
+                       u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds);
     TEC_HIP(ctx, hipGetLastError());
     TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
     ++ctx->kernel_launches;
@@ -295,10 +350,13 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
 
 int tec_bulk_init(tec_ctx* ctx) {
     // 79 KiB of dynamic LDS per workgroup needs the opt-in above the 64 KiB default
-    TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&count_bulk_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
-    TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&count_bulk_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    for (int mixed = 0; mixed < 2; ++mixed)
+        for (int u : {1, 2, 4, 8})
+            TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u)),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
+    const int u = e ? atoi(e) : 2;
+    ctx->unroll = (u == 1 || u == 2 || u == 4 || u == 8) ? u : 2;
     return TEC_OK;
 }
 

@@ -70,6 +70,7 @@ struct tec_ctx {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     int n_cu = 256;
+    int unroll = 2;  // units carried per lane by the count kernel
 };
 
 int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
