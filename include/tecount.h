@@ -36,6 +36,9 @@ extern "C" {
 #define TEC_EENHANCER -5 /* bulk: a read whose only countable type is 'enhancer'; the reference
                             dies with NameError there (te_count.py:145-147, 258-260) */
 #define TEC_EOVERFLOW -6
+#define TEC_ENOCB -7     /* --sc: a record has neither CB nor CR (reference: AssertionError, te_count.py:409) */
+#define TEC_ENOUB -8     /* --sc: a record has neither UB nor UR (reference: AssertionError, te_count.py:426) */
+#define TEC_ENOSTRAND -9 /* --sc: a hit feature has no 'strand' key (reference: KeyError, te_count.py:661) */
 
 /* The reference's bucket width: a semantic constant (te_count/miniglbase/config.py:36). */
 #define TEC_BUCKET_SIZE 10000
@@ -54,7 +57,8 @@ extern "C" {
 #define TEC_META_STRAND_SHIFT 29
 #define TEC_STRAND_PLUS 0  /* '+' */
 #define TEC_STRAND_MINUS 1 /* '-' */
-                           /* 2..7: any other strand string, one id per distinct string */
+                           /* 2..6: any other strand string, one id per distinct string */
+#define TEC_STRAND_MISSING 7 /* the feature has no 'strand' key at all */
 
 /* Record flag bits the path looks at (SAM spec; pysam is_unmapped / is_qcfail / is_duplicate /
  * is_reverse, te_count.py:81-86, 204, 394, 438). */
@@ -148,6 +152,57 @@ int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats);
 /* Duration (ms, HIP events on the stream the kernel runs on) and number of count-kernel
  * launches since tec_bulk_begin; for bench.py's roofline figure. */
 int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* launches);
+
+
+/* ---- Single-cell counting (--sc --se) ------------------------------------------------------
+ * Replaces measureTE.sc_parse_bamse (te_count.py:298-707).  The host decoder hands over, per
+ * record: cls = id of the read-side chromosome string reference_name.replace('chr','')
+ * (te_count.py:431), pos/end = reference_start/reference_end, flag, mapq, the CB (else CR) and
+ * UB (else UR) tag values as zero-padded 24-byte fields, and tagflags (bit 0: CB|CR present,
+ * bit 1: UB|UR present, bit 2: barcode longer than 24 bytes).  Everything the reference keeps in
+ * dicts, sets and spill files stays in HBM; the spill ("bundle") boundaries, the bundle reader's
+ * line-drop rule and the cross-bundle merge are reproduced exactly.
+ *
+ * Call order: begin, submit* (file order), part1, part1_fetch, [host picks the best barcodes,
+ * te_count.py:502], part23, fetch, stats, end.
+ */
+typedef struct tec_sc_stats_t {
+    uint64_t records;         /* submitted                                                     */
+    uint64_t qcfail, lowq;    /* te_count.py:394-400                                           */
+    uint64_t invalid_barcode; /* not on the whitelist (te_count.py:412-415)                    */
+    uint64_t skipped_chrom;   /* '_' or 'alt' chromosomes (te_count.py:432-433)                */
+    uint64_t survivors;       /* records that reach the (CB,UB) collapse                       */
+    uint64_t keys;            /* distinct (CB,UB)                                              */
+    uint64_t bundles;         /* spill epochs                                                  */
+    uint64_t kept_lines;      /* "Preserved N" (te_count.py:545,572)                           */
+    uint64_t assigned;        /* __read_assinged_to_feature (te_count.py:686)                  */
+} tec_sc_stats_t;
+
+/* whitelist24: n_whitelist x 24 bytes, zero padded, strictly ascending bytewise == the order of
+ * sorted(set(lines)) (te_count.py:338): a barcode's id is its row.  bundle_keys: the reference's
+ * literal 1e7 (te_count.py:377).  class_index_chrom[c] = index chrom id of read-side chromosome
+ * string c, or -1 (te_count.py:614); class_skip[c] = '_' in c or 'alt' in c (te_count.py:432). */
+int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n_whitelist, const uint8_t* whitelist24,
+                 uint64_t bundle_keys, uint32_t n_class, const int32_t* class_index_chrom, const uint8_t* class_skip);
+/* Host SoA batch, in file order.  Synchronous: the buffers are free on return. */
+int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const int32_t* pos, const int32_t* end,
+                  const uint16_t* flag, const uint8_t* mapq, const uint8_t* cb24, const uint8_t* ub24,
+                  const uint8_t* tagflags);
+/* Part 1 (te_count.py:371-476).  Returns TEC_ENOCB / TEC_ENOUB where the reference asserts.
+ * *n_cells_seen = number of barcodes with a non-zero raw count. */
+int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen);
+/* Barcodes seen (ascending id), their raw counts (self.barcodes of part 1) and the ordinal of the
+ * record that first counted them (dict insertion order, for the stable sort at te_count.py:502). */
+int tec_sc_part1_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* count, uint64_t* first_seen);
+/* Parts 2 and 3 (te_count.py:493-691) for the selected barcodes (ascending ids). */
+int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint64_t* kept_lines,
+                  uint64_t* n_cells_hit, uint64_t* n_coo);
+/* cell_bcid/cell_hits: self.barcodes of part 3 in insertion order (ascending id);
+ * coo_*: final_results as (barcode id, name id, count) triplets sorted by (barcode, name). */
+int tec_sc_fetch(tec_ctx* ctx, uint32_t* cell_bcid, uint64_t* cell_hits, uint32_t* coo_cell, uint32_t* coo_name,
+                 uint64_t* coo_count);
+int tec_sc_stats(tec_ctx* ctx, tec_sc_stats_t* out);
+int tec_sc_end(tec_ctx* ctx);
 
 #ifdef __cplusplus
 }

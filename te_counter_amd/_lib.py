@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'libtecount.so')
 
 TEC_OK = 0
 TEC_EINVAL, TEC_EHIP, TEC_ENOMEM, TEC_ESTATE, TEC_EENHANCER, TEC_EOVERFLOW = -1, -2, -3, -4, -5, -6
+TEC_ENOCB, TEC_ENOUB, TEC_ENOSTRAND = -7, -8, -9
+STRAND_MISSING = 7
 
 CLASS_OTHER, CLASS_GENE, CLASS_TE, CLASS_SNRNA, CLASS_ENHANCER = 0, 1, 2, 3, 4
 META_NAME_BITS, META_CLASS_SHIFT, META_STRAND_SHIFT = 26, 26, 29
@@ -26,6 +28,11 @@ class TecError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [('units', C.c_uint64), ('assigned', C.c_uint64), ('lowq', C.c_uint64),
                 ('badchrom', C.c_uint64), ('qcfail', C.c_uint64)]
+
+
+class ScStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ('records', 'qcfail', 'lowq', 'invalid_barcode', 'skipped_chrom',
+                                          'survivors', 'keys', 'bundles', 'kept_lines', 'assigned')]
 
 
 _p = C.c_void_p
@@ -48,6 +55,14 @@ _SIGNATURES = {
     'tec_bulk_device_buffers': (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p)]),
     'tec_bulk_finish': (C.c_int, [_p, _p, C.POINTER(Stats)]),
     'tec_bulk_kernel_time': (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    'tec_sc_begin': (C.c_int, [_p, C.c_int, C.c_int, C.c_uint32, _p, _u64, C.c_uint32, _p, _p]),
+    'tec_sc_submit': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'tec_sc_part1': (C.c_int, [_p, C.POINTER(_u64)]),
+    'tec_sc_part1_fetch': (C.c_int, [_p, _p, _p, _p]),
+    'tec_sc_part23': (C.c_int, [_p, C.c_uint32, _p, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    'tec_sc_fetch': (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    'tec_sc_stats': (C.c_int, [_p, C.POINTER(ScStats)]),
+    'tec_sc_end': (C.c_int, [_p]),
 }
 
 _lib = None

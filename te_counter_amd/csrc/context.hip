@@ -58,6 +58,8 @@ extern "C" void tec_destroy(tec_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     tec_bulk_release(ctx);
+    tec_sc_release(ctx);
+    if (ctx->d_int2ext) (void)hipFree(ctx->d_int2ext);
     if (ctx->d_index_blob) (void)hipFree(ctx->d_index_blob);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);

@@ -6,7 +6,7 @@
 //
 // Layout (all chromosomes concatenated, one blob in HBM):
 //   bin_off[n_bins + 1]   u32 CSR offsets; a chromosome's fine bins are contiguous
-//   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by name id inside a fine bin
+//   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by (name id, strand) inside a fine bin
 //   chrom_base[n_chrom], chrom_nbins[n_chrom]
 // A feature [left, right] is filed under every fine bin (2^shift bp) that intersects
 // [left-1, right+1]: any read edge that can pass one of the reference's 2-bp edge tests
@@ -134,6 +134,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
             std::sort(entries.begin() + a, entries.begin() + z, [&](const tec_entry& x, const tec_entry& y) {
                 const uint32_t nx = x.meta & name_mask, ny = y.meta & name_mask;
                 if (nx != ny) return nx < ny;
+                const uint32_t sx = x.meta >> TEC_META_STRAND_SHIFT, sy = y.meta >> TEC_META_STRAND_SHIFT;
+                if (sx != sy) return sx < sy;  // (name, strand) pairs adjacent: single-cell dedupe
                 if (x.left != y.left) return x.left < y.left;
                 if (x.right != y.right) return x.right < y.right;
                 return x.meta < y.meta;
@@ -156,15 +158,21 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (e == hipSuccess) e = hipMemcpy(p + o_cb, chrom_base.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cn, chrom_nbins.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     unsigned long long* counts = nullptr;
+    uint32_t* d_i2e = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_i2e, (size_t)n_names * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_i2e, int2ext.data(), (size_t)n_names * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&counts, (size_t)n_names * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(counts, 0, (size_t)n_names * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipFree(blob);
         if (counts) (void)hipFree(counts);
+        if (d_i2e) (void)hipFree(d_i2e);
         return tec_fail(ctx, TEC_EHIP, "tec_index_build: upload failed: %s", hipGetErrorString(e));
     }
     if (ctx->d_index_blob) (void)hipFree(ctx->d_index_blob);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_int2ext) (void)hipFree(ctx->d_int2ext);
+    ctx->d_int2ext = d_i2e;
     ctx->d_index_blob = blob;
     ctx->d_counts = counts;
     ctx->idx.bin_off = reinterpret_cast<const uint32_t*>(p + o_off);

@@ -1,0 +1,1001 @@
+// Single-cell (--sc --se) counting on gfx950: tec_sc_* entry points.
+//
+// Replaces measureTE.sc_parse_bamse (te_count/te_count.py:298-707).  The reference streams the
+// BAM once, keeps a dict of (CB,UB) -> set of "chrom:strand:left:rite" strings, spills it to a
+// sorted text "bundle" every 1e7 keys, k-way merges the bundles for the best cells and finally
+// maps what is left to features.  Here every record that survives the filters stays resident in
+// HBM (32-48 B per record: 288 GB holds billions), and the three parts become whole-array
+// passes:
+//
+//   submit   filters (te_count.py:394-433): flags, mapq, CB|CR present, whitelist lookup (binary
+//            search over the sorted, byte-packed whitelist -> id = rank, te_count.py:338,418),
+//            UB|UR present, '_'/'alt' chromosomes; order-preserving compaction of survivors
+//   part 1   stable LSD radix sort by (barcode id, UMI bytes) -> records of one key are adjacent
+//            and in file order.  Epochs ("bundles", te_count.py:377-390) are recovered exactly:
+//            the epoch ends at the record that creates the bundle_keys-th distinct key since the
+//            last flush.  Inside an (epoch, key) instance the first record supplies the stored
+//            string; later records of the same class are duplicates (te_count.py:452-454), a
+//            record of another class adds a string (te_count.py:457-462).  Per-barcode counts.
+//   part 2   (host picks the maxcells+1000 best barcodes, te_count.py:502)  bundle line order =
+//            instance heads sorted by (epoch, barcode, UMI); the reference's reader drops a line
+//            iff it is the first of its bundle or a selected barcode lies in [BC(prev), BC(line))
+//            (te_count.py:509-543); across bundles the first kept line of a key wins (:552-555)
+//   part 3   per surviving (key, class): all-bucket candidate rule + the two inclusive 2-bp
+//            window tests (te_count.py:619-649), distinct (name, strand) pairs, type branch with
+//            the strand filter (te_count.py:660-684) -> (cell, name) keys, sorted + run-length
+//            encoded into COO triplets.
+#include <cstring>  // before rocprim: its texture iterator calls the host memset
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+#include "tecount_internal.h"
+
+namespace {
+
+constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
+constexpr uint32_t kPairMask = ~(7u << TEC_META_CLASS_SHIFT);  // name | strand
+constexpr int kB = 256;
+
+template <class T>
+struct dvec {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n, bool keep = false, size_t used = 0) {
+        if (n <= cap) return hipSuccess;
+        size_t want = std::max(n, cap + cap / 2);
+        T* q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(want, 1) * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && used) e = hipMemcpy(q, p, used * sizeof(T), hipMemcpyDeviceToDevice);
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_OR0, ST_OR1, ST_OR2, ST_NOSTRAND, ST_N };
+
+}  // namespace
+
+struct tec_sc_state {
+    int stranded = 0, mapq_min = 20;
+    uint64_t bundle_keys = 10000000;
+    uint32_t n_wl = 0, n_class = 0;
+    dvec<uint64_t> wl;          // 3 words per barcode, big-endian packed, ascending
+    dvec<int32_t> cls_chrom;    // read-side chromosome class -> index chrom id (-1: not in index)
+    dvec<uint8_t> cls_skip;     // '_' or 'alt' in the read-side chromosome string
+    // survivors, in file order
+    dvec<uint32_t> bcid;
+    dvec<uint64_t> u0, u1, u2, rec;
+    dvec<int32_t> klass, left, rite;
+    uint64_t n_live = 0, n_seen = 0;
+    dvec<unsigned long long> stat;
+    // batch temporaries
+    dvec<uint32_t> b_live, b_scan, b_bcid;
+    dvec<char> b_in, tmp;
+    // sorted views (part 1)
+    dvec<uint32_t> perm, perm2, s_bcid, gid, s_epoch, headidx, cnt, first_seen;
+    dvec<uint64_t> k64a, k64b, s_u0, s_u1, s_u2;
+    dvec<uint32_t> k32a, k32b;
+    dvec<int32_t> s_klass, s_left, s_rite;
+    dvec<uint8_t> ghead, ihead, counted;
+    uint32_t n_groups = 0, n_epochs = 1;
+    bool part1_done = false;
+    std::vector<uint32_t> cells_seen;
+    std::vector<uint64_t> cells_count, cells_first;
+    // results
+    std::vector<uint32_t> out_cell, coo_cell, coo_name;
+    std::vector<uint64_t> out_hits, coo_count;
+    uint64_t kept_lines = 0, n_queries = 0, n_assigned = 0;
+    unsigned long long h_stat[ST_N] = {0};
+};
+
+namespace {
+
+#define SC_HIP(call) TEC_HIP(ctx, call)
+
+__device__ __forceinline__ uint64_t load_be64(const uint8_t* p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+
+// rank of the 24-byte key in the sorted whitelist, or -1
+__device__ __forceinline__ int wl_find(const uint64_t* __restrict__ wl, uint32_t n, uint64_t a, uint64_t b, uint64_t c) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint64_t x = wl[3 * (size_t)mid], y = wl[3 * (size_t)mid + 1], z = wl[3 * (size_t)mid + 2];
+        const bool less = x < a || (x == a && (y < b || (y == b && z < c)));
+        if (less)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < n && wl[3 * (size_t)lo] == a && wl[3 * (size_t)lo + 1] == b && wl[3 * (size_t)lo + 2] == c) return (int)lo;
+    return -1;
+}
+
+__device__ __forceinline__ void wave_add(unsigned long long* ctr, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
+}
+
+// te_count.py:394-433, in the reference's order.
+__global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* __restrict__ cls,
+                                 const uint16_t* __restrict__ flag, const uint8_t* __restrict__ mapq,
+                                 const uint8_t* __restrict__ cb, const uint8_t* __restrict__ tagflags, int mapq_min,
+                                 const uint64_t* __restrict__ wl, uint32_t n_wl, const uint8_t* __restrict__ cls_skip,
+                                 uint32_t n_class, uint32_t* live, uint32_t* bcid_out, unsigned long long* stat) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool qc = false, lowq = false, badbc = false, skipc = false, ok = false;
+    if (i < n) {
+        const unsigned fl = flag[i];
+        const unsigned tf = tagflags[i];
+        if (fl & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
+            qc = true;
+        } else if ((int)mapq[i] < mapq_min) {
+            lowq = true;
+        } else if (!(tf & 1u)) {
+            atomicMin(&stat[ST_NOCB], (unsigned long long)(rec_base + i));  // AssertionError('CB or CR tag not found!')
+        } else {
+            int id = -1;
+            if (!(tf & 4u)) {  // bit 2: barcode longer than 24 bytes, cannot be on the whitelist
+                const uint8_t* p = cb + 24 * i;
+                id = wl_find(wl, n_wl, load_be64(p), load_be64(p + 8), load_be64(p + 16));
+            }
+            if (id < 0) {
+                badbc = true;
+            } else if (!(tf & 2u)) {
+                atomicMin(&stat[ST_NOUB], (unsigned long long)(rec_base + i));  // AssertionError('UB or UR tag not found!')
+            } else {
+                const int c = cls[i];
+                if (c < 0 || (uint32_t)c >= n_class || cls_skip[c]) {
+                    skipc = true;
+                } else {
+                    ok = true;
+                    bcid_out[i] = (uint32_t)id;
+                }
+            }
+        }
+        live[i] = ok ? 1u : 0u;
+    }
+    wave_add(&stat[ST_QCFAIL], qc);
+    wave_add(&stat[ST_LOWQ], lowq);
+    wave_add(&stat[ST_BADBC], badbc);
+    wave_add(&stat[ST_SKIPCHROM], skipc);
+}
+
+__global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, uint64_t out_base, const uint32_t* __restrict__ live,
+                                  const uint32_t* __restrict__ scan, const uint32_t* __restrict__ bcid_in,
+                                  const int32_t* __restrict__ cls, const int32_t* __restrict__ pos,
+                                  const int32_t* __restrict__ end, const uint16_t* __restrict__ flag,
+                                  const uint8_t* __restrict__ ub, int stranded, uint32_t* bcid, uint64_t* u0,
+                                  uint64_t* u1, uint64_t* u2, uint64_t* rec, int32_t* klass, int32_t* left, int32_t* rite,
+                                  unsigned long long* stat) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t a = 0, b = 0, c = 0;
+    if (i < n && live[i]) {
+        const uint64_t o = out_base + scan[i];
+        const uint8_t* p = ub + 24 * i;
+        a = load_be64(p);
+        b = load_be64(p + 8);
+        c = load_be64(p + 16);
+        bcid[o] = bcid_in[i];
+        u0[o] = a;
+        u1[o] = b;
+        u2[o] = c;
+        rec[o] = rec_base + i;
+        klass[o] = (cls[i] << 1) | ((stranded && (flag[i] & TEC_FLAG_REVERSE)) ? 1 : 0);
+        left[o] = pos[i];
+        rite[o] = end[i];
+    }
+    // which UMI bits are ever set: bounds the radix passes of part 1
+    for (int off = 32; off > 0; off >>= 1) {
+        a |= __shfl_down(a, off, 64);
+        b |= __shfl_down(b, off, 64);
+        c |= __shfl_down(c, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicOr(&stat[ST_OR0], (unsigned long long)a);
+        if (b) atomicOr(&stat[ST_OR1], (unsigned long long)b);
+        if (c) atomicOr(&stat[ST_OR2], (unsigned long long)c);
+    }
+}
+
+template <class T>
+__global__ void gather_kernel(uint64_t n, const uint32_t* __restrict__ perm, const T* __restrict__ src, T* dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+__global__ void iota_kernel(uint64_t n, uint32_t* p) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+
+__global__ void ghead_kernel(uint64_t n, const uint32_t* __restrict__ bc, const uint64_t* __restrict__ u0,
+                             const uint64_t* __restrict__ u1, const uint64_t* __restrict__ u2, uint8_t* ghead,
+                             uint32_t* ghead32) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool h = i == 0 || bc[i] != bc[i - 1] || u0[i] != u0[i - 1] || u1[i] != u1[i - 1] || u2[i] != u2[i - 1];
+    ghead[i] = h;
+    ghead32[i] = h;
+}
+
+// Marks, in file-order (ordinal) space, the first record of every key after ordinal `lower`.
+__global__ void epoch_mark_kernel(uint64_t n, const uint32_t* __restrict__ ord, const uint8_t* __restrict__ ghead,
+                                  long long lower, uint32_t* mark_by_ord) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long o = ord[i];
+    const bool m = o > lower && (ghead[i] || (long long)ord[i - 1] <= lower);
+    mark_by_ord[o] = m ? 1u : 0u;
+}
+
+__global__ void epoch_find_kernel(uint64_t n, const uint32_t* __restrict__ mark, const uint32_t* __restrict__ cum,
+                                  uint32_t target, unsigned long long* out) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n && mark[o] && cum[o] == target) *out = o;
+}
+
+__global__ void epoch_assign_kernel(uint64_t n, const uint32_t* __restrict__ ord, const uint32_t* __restrict__ bounds,
+                                    uint32_t n_bounds, uint32_t* epoch) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = n_bounds;  // number of boundaries strictly below this ordinal
+    const uint32_t o = ord[i];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bounds[mid] < o)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    epoch[i] = lo;
+}
+
+__global__ void ihead_kernel(uint64_t n, const uint8_t* __restrict__ ghead, const uint32_t* __restrict__ epoch,
+                             uint8_t* ihead, uint32_t* headpos) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool h = ghead[i] || epoch[i] != epoch[i - 1];
+    ihead[i] = h;
+    headpos[i] = h ? (uint32_t)i : 0u;
+}
+
+// counted = a string is stored / the barcode counter bumps (te_count.py:457-473)
+__global__ void part1_count_kernel(uint64_t n, const uint8_t* __restrict__ ihead, const uint32_t* __restrict__ headidx,
+                                   const int32_t* __restrict__ klass, const uint32_t* __restrict__ bc,
+                                   const uint32_t* __restrict__ ord, uint8_t* counted, uint32_t* cnt,
+                                   uint32_t* first_seen) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool c = ihead[i] || klass[i] != klass[headidx[i]];
+    counted[i] = c;
+    if (c) {
+        atomicAdd(&cnt[bc[i]], 1u);
+        atomicMin(&first_seen[bc[i]], ord[i]);
+    }
+}
+
+__global__ void flag_from_u8_kernel(uint64_t n, const uint8_t* __restrict__ f, uint32_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f[i];
+}
+
+__global__ void compact_idx_kernel(uint64_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan,
+                                   uint32_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[scan[i]] = (uint32_t)i;
+}
+
+__global__ void scatter_sel_kernel(uint32_t n, const uint32_t* __restrict__ sel_ids, uint32_t* sel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sel[sel_ids[i]] = 1u;
+}
+
+// The bundle reader's drop rule (te_count.py:509-543), one thread per bundle line.
+__global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_rec, const uint32_t* __restrict__ bc,
+                            const uint32_t* __restrict__ epoch, const uint32_t* __restrict__ sel,
+                            const uint32_t* __restrict__ selprefix, const uint32_t* __restrict__ gid, uint8_t* kept_rec,
+                            uint32_t* firstkept, unsigned long long* n_kept) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool k = false;
+    if (j < n_lines) {
+        const uint32_t i = line_rec[j];
+        if (j > 0) {
+            const uint32_t p = line_rec[j - 1];
+            if (epoch[p] == epoch[i] && sel[bc[i]]) k = bc[p] == bc[i] || selprefix[bc[i]] == selprefix[bc[p]];
+        }
+        kept_rec[i] = k;
+        if (k) atomicMin(&firstkept[gid[i]], i);
+    }
+    wave_add(n_kept, k);
+}
+
+// A record feeds part 3 iff its instance survived part 2 and it is the head, or an extra string
+// that no later extra of the same class overwrites (reads[(chrom,strand)] = ..., te_count.py:606).
+__global__ void query_flag_kernel(uint64_t n, const uint8_t* __restrict__ ihead, const uint8_t* __restrict__ counted,
+                                  const uint32_t* __restrict__ headidx, const uint8_t* __restrict__ kept_rec,
+                                  const uint32_t* __restrict__ firstkept, const uint32_t* __restrict__ gid,
+                                  const int32_t* __restrict__ klass, uint32_t* qflag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = headidx[i];
+    bool q = counted[i] && kept_rec[h] && firstkept[gid[h]] == h;
+    if (q && !ihead[i]) {
+        for (uint64_t x = i + 1; x < n && !ihead[x]; ++x)
+            if (counted[x] && klass[x] == klass[i]) {
+                q = false;
+                break;
+            }
+    }
+    qflag[i] = q ? 1u : 0u;
+}
+
+__device__ __forceinline__ int bucket_of(int x) { return x < 0 ? -1 : (int)((unsigned)x / (unsigned)TEC_BUCKET_SIZE); }
+
+struct ScQuery {
+    int left, rite, blo, bhi;
+};
+// te_count.py:645 / :648 (inclusive windows) and :619-634 (every bucket from (left-1)//bs to rite//bs)
+__device__ __forceinline__ bool sc_t1(const tec_entry& e, const ScQuery& q) { return (long long)q.left + 1 >= e.left && q.left <= e.right; }
+__device__ __forceinline__ bool sc_t2(const tec_entry& e, const ScQuery& q) { return q.rite >= e.left && (long long)q.rite - 1 <= e.right; }
+__device__ __forceinline__ bool sc_cand(const tec_entry& e, const ScQuery& q) {
+    return q.bhi >= q.blo && bucket_of(e.left) <= q.bhi && bucket_of(e.right) >= q.blo;
+}
+__device__ __forceinline__ int floor_bucket(long long x) {
+    long long b = x / TEC_BUCKET_SIZE;
+    if (x - b * TEC_BUCKET_SIZE < 0) --b;
+    return (int)b;
+}
+
+__device__ __forceinline__ void sc_range(const tec_index_dev& idx, int chrom, int pos, uint32_t* a, uint32_t* z) {
+    *a = *z = 0;
+    if (pos < -1) return;
+    const uint32_t b = (uint32_t)(pos < 0 ? 0 : pos) >> idx.shift;
+    if (b >= idx.chrom_nbins[chrom]) return;
+    const uint32_t g = idx.chrom_base[chrom] + b;
+    *a = idx.bin_off[g];
+    *z = idx.bin_off[g + 1];
+}
+
+// Part 3 for one (cell, class, left, rite).  EMIT=false: returns the number of (cell, name)
+// increments; EMIT=true: writes them.  Also bumps the per-cell "mapped to something" counter.
+template <bool EMIT>
+__global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* __restrict__ qrec,
+                                const uint32_t* __restrict__ bc, const int32_t* __restrict__ klass,
+                                const int32_t* __restrict__ left, const int32_t* __restrict__ rite,
+                                const int32_t* __restrict__ cls_chrom, int stranded, uint32_t* n_emit,
+                                const uint32_t* __restrict__ emit_off, uint64_t* keys, uint32_t* cellhits,
+                                unsigned long long* stat, unsigned long long* n_assigned) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq) return;
+    const uint32_t i = qrec[t];
+    const int kl = klass[i];
+    const int chrom = cls_chrom[kl >> 1];
+    uint32_t emitted = 0;
+    uint64_t* out = EMIT ? keys + emit_off[t] : nullptr;
+    if (chrom >= 0) {
+        ScQuery q;
+        q.left = left[i];
+        q.rite = rite[i];
+        q.blo = floor_bucket((long long)q.left - 1);
+        q.bhi = floor_bucket((long long)q.rite);
+        uint32_t a0, a1, b0, b1;
+        sc_range(idx, chrom, q.left, &a0, &a1);
+        sc_range(idx, chrom, q.rite, &b0, &b1);
+        const tec_entry* __restrict__ ent = idx.entries;
+        const bool one = a0 == b0 && a1 == b1;
+        // pass 1: which classes are hit
+        uint32_t classes = 0;
+        bool nostrand = false;
+        for (uint32_t j = a0; j < a1; ++j) {
+            const tec_entry e = ent[j];
+            if ((sc_t1(e, q) || (one && sc_t2(e, q))) && sc_cand(e, q)) {
+                classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
+                nostrand |= (e.meta >> TEC_META_STRAND_SHIFT) == 7u;
+            }
+        }
+        if (!one)
+            for (uint32_t j = b0; j < b1; ++j) {
+                const tec_entry e = ent[j];
+                if (sc_t2(e, q) && sc_cand(e, q)) {
+                    classes |= 1u << ((e.meta >> TEC_META_CLASS_SHIFT) & 7u);
+                    nostrand |= (e.meta >> TEC_META_STRAND_SHIFT) == 7u;
+                }
+            }
+        if (classes) {
+            if (!EMIT) {
+                atomicAdd(&cellhits[bc[i]], 1u);  // self.barcodes[barcode] += 1 (te_count.py:653-655)
+                if (nostrand) atomicAdd(&stat[ST_NOSTRAND], 1ull);  // KeyError: 'strand' (te_count.py:661)
+            }
+            const bool gene = classes & (1u << TEC_CLASS_GENE);
+            const bool other = classes & ((1u << TEC_CLASS_TE) | (1u << TEC_CLASS_ENHANCER));
+            if (gene || other) {
+                if (!EMIT) atomicAdd(n_assigned, 1ull);
+                const uint32_t rs = (uint32_t)(kl & 1);
+                const uint64_t cell = (uint64_t)bc[i] << 32;
+                uint32_t last = 0xFFFFFFFFu;
+                auto emit = [&](uint32_t pair) {
+                    // gene branch: antisense pairs are skipped when --strand (te_count.py:665)
+                    if (gene && stranded && (pair >> TEC_META_STRAND_SHIFT) != rs) return;
+                    if (EMIT) out[emitted] = cell | (pair & kNameMask);
+                    ++emitted;
+                };
+                for (uint32_t j = a0; j < a1; ++j) {
+                    const tec_entry e = ent[j];
+                    if ((sc_t1(e, q) || (one && sc_t2(e, q))) && sc_cand(e, q)) {
+                        const uint32_t pair = e.meta & kPairMask;
+                        if (pair != last) emit(pair);
+                        last = pair;
+                    }
+                }
+                if (!one) {
+                    last = 0xFFFFFFFFu;
+                    for (uint32_t j = b0; j < b1; ++j) {
+                        const tec_entry e = ent[j];
+                        if (sc_t2(e, q) && sc_cand(e, q)) {
+                            const uint32_t pair = e.meta & kPairMask;
+                            if (pair != last) {
+                                bool seen = false;
+                                for (uint32_t k = a0; k < a1 && !seen; ++k) {
+                                    const tec_entry f = ent[k];
+                                    seen = (f.meta & kPairMask) == pair && sc_t1(f, q) && sc_cand(f, q);
+                                }
+                                if (!seen) emit(pair);
+                            }
+                            last = pair;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!EMIT) n_emit[t] = emitted;
+}
+
+__global__ void map_names_kernel(uint64_t n, uint64_t* keys, const uint32_t* __restrict__ int2ext) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (keys[i] & 0xFFFFFFFF00000000ull) | int2ext[keys[i] & 0xFFFFFFFFull];
+}
+
+inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kB - 1) / kB); }
+
+template <class T>
+int scan_u32(tec_ctx* ctx, tec_sc_state* s, const uint32_t* in, uint32_t* out, size_t n, bool inclusive, T op) {
+    size_t bytes = 0;
+    if (inclusive)
+        SC_HIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, op, ctx->s_compute));
+    else
+        SC_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, op, ctx->s_compute));
+    SC_HIP(s->tmp.reserve(bytes));
+    if (inclusive)
+        SC_HIP(rocprim::inclusive_scan(s->tmp.p, bytes, in, out, n, op, ctx->s_compute));
+    else
+        SC_HIP(rocprim::exclusive_scan(s->tmp.p, bytes, in, out, 0u, n, op, ctx->s_compute));
+    return TEC_OK;
+}
+
+template <class K>
+int sort_pairs(tec_ctx* ctx, tec_sc_state* s, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
+               unsigned b0, unsigned b1) {
+    size_t bytes = 0;
+    SC_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, ctx->s_compute));
+    SC_HIP(s->tmp.reserve(bytes));
+    SC_HIP(rocprim::radix_sort_pairs(s->tmp.p, bytes, kin, kout, vin, vout, n, b0, b1, ctx->s_compute));
+    return TEC_OK;
+}
+
+inline unsigned bits_for(uint64_t max_value) {
+    unsigned b = 1;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b;
+}
+
+void sc_free(tec_sc_state* s) {
+    if (!s) return;
+    s->wl.release(); s->cls_chrom.release(); s->cls_skip.release();
+    s->bcid.release(); s->u0.release(); s->u1.release(); s->u2.release(); s->rec.release();
+    s->klass.release(); s->left.release(); s->rite.release(); s->stat.release();
+    s->b_live.release(); s->b_scan.release(); s->b_bcid.release(); s->b_in.release(); s->tmp.release();
+    s->perm.release(); s->perm2.release(); s->s_bcid.release(); s->gid.release(); s->s_epoch.release();
+    s->headidx.release(); s->cnt.release(); s->first_seen.release(); s->k64a.release(); s->k64b.release();
+    s->s_u0.release(); s->s_u1.release(); s->s_u2.release(); s->k32a.release(); s->k32b.release();
+    s->s_klass.release(); s->s_left.release(); s->s_rite.release(); s->ghead.release(); s->ihead.release();
+    s->counted.release();
+    delete s;
+}
+
+}  // namespace
+
+void tec_sc_release(tec_ctx* ctx) {
+    sc_free(ctx->sc);
+    ctx->sc = nullptr;
+}
+
+extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n_whitelist, const uint8_t* whitelist24,
+                            uint64_t bundle_keys, uint32_t n_class, const int32_t* class_index_chrom,
+                            const uint8_t* class_skip) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: NULL context");
+    if (!ctx->have_index) return tec_fail(ctx, TEC_ESTATE, "tec_sc_begin: no index resident");
+    if (n_whitelist == 0 || !whitelist24) return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: empty whitelist");
+    if (n_class && (!class_index_chrom || !class_skip)) return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: NULL class table");
+    if (bundle_keys == 0) return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: bundle_keys must be positive");
+    SC_HIP(hipSetDevice(ctx->device));
+    tec_sc_release(ctx);
+    tec_sc_state* s = new tec_sc_state();
+    ctx->sc = s;
+    s->stranded = stranded ? 1 : 0;
+    s->mapq_min = mapq_min;
+    s->bundle_keys = bundle_keys;
+    s->n_wl = n_whitelist;
+    s->n_class = n_class;
+    std::vector<uint64_t> packed(3 * (size_t)n_whitelist);
+    for (size_t i = 0; i < n_whitelist; ++i)
+        for (int w = 0; w < 3; ++w) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; ++b) v = (v << 8) | whitelist24[24 * i + 8 * w + b];
+            packed[3 * i + w] = v;
+        }
+    for (size_t i = 1; i < n_whitelist; ++i) {
+        const uint64_t* a = &packed[3 * (i - 1)];
+        const uint64_t* b = &packed[3 * i];
+        if (!(a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[2] < b[2])))))
+            return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: whitelist must be strictly ascending (entry %zu)", i);
+    }
+    SC_HIP(s->wl.reserve(packed.size()));
+    SC_HIP(hipMemcpy(s->wl.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
+    SC_HIP(s->cls_chrom.reserve(std::max<uint32_t>(n_class, 1)));
+    SC_HIP(s->cls_skip.reserve(std::max<uint32_t>(n_class, 1)));
+    if (n_class) {
+        SC_HIP(hipMemcpy(s->cls_chrom.p, class_index_chrom, n_class * 4, hipMemcpyHostToDevice));
+        SC_HIP(hipMemcpy(s->cls_skip.p, class_skip, n_class, hipMemcpyHostToDevice));
+    }
+    SC_HIP(s->stat.reserve(ST_N));
+    unsigned long long init[ST_N] = {0};
+    init[ST_NOCB] = init[ST_NOUB] = ~0ull;
+    SC_HIP(hipMemcpy(s->stat.p, init, sizeof init, hipMemcpyHostToDevice));
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const int32_t* pos, const int32_t* end,
+                             const uint16_t* flag, const uint8_t* mapq, const uint8_t* cb24, const uint8_t* ub24,
+                             const uint8_t* tagflags) {
+    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "tec_sc_submit: call tec_sc_begin first");
+    tec_sc_state* s = ctx->sc;
+    if (s->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_submit: after tec_sc_part1");
+    if (n == 0) return TEC_OK;
+    if (!cls || !pos || !end || !flag || !mapq || !cb24 || !ub24 || !tagflags)
+        return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit: NULL array");
+    if (n >= 0x7FFFFFFFull) return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit: batch too large");
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    // stage the batch: cls | pos | end | flag | mapq | tagflags | cb | ub
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t o_cls = 0, o_pos = o_cls + al(n * 4), o_end = o_pos + al(n * 4), o_flag = o_end + al(n * 4),
+                 o_mq = o_flag + al(n * 2), o_tf = o_mq + al(n), o_cb = o_tf + al(n), o_ub = o_cb + al(n * 24),
+                 total = o_ub + al(n * 24);
+    SC_HIP(s->b_in.reserve(total));
+    char* b = s->b_in.p;
+    SC_HIP(hipMemcpyAsync(b + o_cls, cls, n * 4, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_pos, pos, n * 4, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_end, end, n * 4, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_flag, flag, n * 2, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_mq, mapq, n, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_tf, tagflags, n, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_cb, cb24, n * 24, hipMemcpyHostToDevice, st));
+    SC_HIP(hipMemcpyAsync(b + o_ub, ub24, n * 24, hipMemcpyHostToDevice, st));
+    SC_HIP(s->b_live.reserve(n));
+    SC_HIP(s->b_scan.reserve(n));
+    SC_HIP(s->b_bcid.reserve(n));
+    hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, (const int32_t*)(b + o_cls),
+                       (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_mq), (const uint8_t*)(b + o_cb),
+                       (const uint8_t*)(b + o_tf), s->mapq_min, s->wl.p, s->n_wl, s->cls_skip.p, s->n_class, s->b_live.p,
+                       s->b_bcid.p, s->stat.p);
+    int rc = scan_u32(ctx, s, s->b_live.p, s->b_scan.p, n, false, rocprim::plus<uint32_t>());
+    if (rc) return rc;
+    uint32_t last_scan = 0, last_live = 0;
+    SC_HIP(hipMemcpyAsync(&last_scan, s->b_scan.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(&last_live, s->b_live.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    const uint64_t add = (uint64_t)last_scan + last_live;
+    const uint64_t need = s->n_live + add;
+    if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
+    SC_HIP(s->bcid.reserve(need, true, s->n_live));
+    SC_HIP(s->u0.reserve(need, true, s->n_live));
+    SC_HIP(s->u1.reserve(need, true, s->n_live));
+    SC_HIP(s->u2.reserve(need, true, s->n_live));
+    SC_HIP(s->rec.reserve(need, true, s->n_live));
+    SC_HIP(s->klass.reserve(need, true, s->n_live));
+    SC_HIP(s->left.reserve(need, true, s->n_live));
+    SC_HIP(s->rite.reserve(need, true, s->n_live));
+    hipLaunchKernelGGL(sc_scatter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, s->n_live, s->b_live.p,
+                       s->b_scan.p, s->b_bcid.p, (const int32_t*)(b + o_cls), (const int32_t*)(b + o_pos),
+                       (const int32_t*)(b + o_end), (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_ub), s->stranded,
+                       s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p, s->klass.p, s->left.p, s->rite.p, s->stat.p);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(st));  // host buffers are free again, staging can be reused
+    s->n_live = need;
+    s->n_seen += n;
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
+    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part1: call tec_sc_begin first");
+    tec_sc_state* s = ctx->sc;
+    if (s->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part1: already done");
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    SC_HIP(hipStreamSynchronize(st));
+    SC_HIP(hipMemcpy(s->h_stat, s->stat.p, sizeof s->h_stat, hipMemcpyDeviceToHost));
+    s->part1_done = true;
+    s->cells_seen.clear();
+    s->cells_count.clear();
+    s->cells_first.clear();
+    if (n_cells_seen) *n_cells_seen = 0;
+    // the reference dies at the first record (file order) that lacks a tag
+    if (s->h_stat[ST_NOCB] != ~0ull || s->h_stat[ST_NOUB] != ~0ull) {
+        if (s->h_stat[ST_NOCB] < s->h_stat[ST_NOUB])
+            return tec_fail(ctx, TEC_ENOCB, "CB or CR tag not found! (record %llu)", s->h_stat[ST_NOCB]);
+        return tec_fail(ctx, TEC_ENOUB, "UB or UR tag not found! (record %llu)", s->h_stat[ST_NOUB]);
+    }
+    const uint64_t N = s->n_live;
+    if (N == 0) return TEC_OK;
+    const unsigned g = grid_for(N);
+
+    // ---- stable LSD radix sort of a permutation by (bcid, u0, u1, u2)
+    SC_HIP(s->perm.reserve(N));
+    SC_HIP(s->perm2.reserve(N));
+    SC_HIP(s->k64a.reserve(N));
+    SC_HIP(s->k64b.reserve(N));
+    SC_HIP(s->k32a.reserve(N));
+    SC_HIP(s->k32b.reserve(N));
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p);
+    const uint64_t* words[3] = {s->u2.p, s->u1.p, s->u0.p};
+    const unsigned long long masks[3] = {s->h_stat[ST_OR2], s->h_stat[ST_OR1], s->h_stat[ST_OR0]};
+    for (int w = 0; w < 3; ++w) {
+        if (!masks[w]) continue;
+        const unsigned b0 = (unsigned)__builtin_ctzll(masks[w]), b1 = 64u - (unsigned)__builtin_clzll(masks[w]);
+        hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, words[w], s->k64a.p);
+        int rc = sort_pairs(ctx, s, s->k64a.p, s->k64b.p, s->perm.p, s->perm2.p, N, b0, b1);
+        if (rc) return rc;
+        std::swap(s->perm.p, s->perm2.p);
+        std::swap(s->perm.cap, s->perm2.cap);
+    }
+    {
+        hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->bcid.p, s->k32a.p);
+        int rc = sort_pairs(ctx, s, s->k32a.p, s->k32b.p, s->perm.p, s->perm2.p, N, 0, bits_for(s->n_wl));
+        if (rc) return rc;
+        std::swap(s->perm.p, s->perm2.p);
+        std::swap(s->perm.cap, s->perm2.cap);
+    }
+    // ---- sorted views
+    SC_HIP(s->s_bcid.reserve(N));
+    SC_HIP(s->s_u0.reserve(N));
+    SC_HIP(s->s_u1.reserve(N));
+    SC_HIP(s->s_u2.reserve(N));
+    SC_HIP(s->s_klass.reserve(N));
+    SC_HIP(s->s_left.reserve(N));
+    SC_HIP(s->s_rite.reserve(N));
+    hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->bcid.p, s->s_bcid.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u0.p, s->s_u0.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u1.p, s->s_u1.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u2.p, s->s_u2.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->klass.p, s->s_klass.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->left.p, s->s_left.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->rite.p, s->s_rite.p);
+    // ---- keys (groups)
+    SC_HIP(s->ghead.reserve(N));
+    SC_HIP(s->gid.reserve(N));
+    hipLaunchKernelGGL(ghead_kernel, dim3(g), dim3(kB), 0, st, N, s->s_bcid.p, s->s_u0.p, s->s_u1.p, s->s_u2.p, s->ghead.p,
+                       s->k32a.p);
+    int rc = scan_u32(ctx, s, s->k32a.p, s->gid.p, N, true, rocprim::plus<uint32_t>());
+    if (rc) return rc;
+    uint32_t last_gid = 0;
+    SC_HIP(hipMemcpyAsync(&last_gid, s->gid.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    s->n_groups = last_gid;  // inclusive scan of heads: the last value is the number of keys
+    // gid = scan - 1 is only used as an array index: keep scan value and subtract at use sites
+    // ---- epochs (te_count.py:377-390): the flush fires once len(umis) has reached bundle_keys
+    std::vector<uint32_t> bounds;
+    if ((uint64_t)s->n_groups >= s->bundle_keys) {
+        long long lower = -1;
+        unsigned long long* d_found = s->stat.p + ST_N - 1;  // scratch word (ST_NOSTRAND is reset below)
+        for (;;) {
+            hipLaunchKernelGGL(epoch_mark_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->ghead.p, lower, s->k32a.p);
+            rc = scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, true, rocprim::plus<uint32_t>());
+            if (rc) return rc;
+            uint32_t total = 0;
+            SC_HIP(hipMemcpyAsync(&total, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+            SC_HIP(hipStreamSynchronize(st));
+            if ((uint64_t)total < s->bundle_keys) break;
+            const unsigned long long none = ~0ull;
+            SC_HIP(hipMemcpyAsync(d_found, &none, 8, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(epoch_find_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p,
+                               (uint32_t)s->bundle_keys, d_found);
+            unsigned long long found = none;
+            SC_HIP(hipMemcpyAsync(&found, d_found, 8, hipMemcpyDeviceToHost, st));
+            SC_HIP(hipStreamSynchronize(st));
+            if (found == none) return tec_fail(ctx, TEC_EHIP, "tec_sc_part1: epoch boundary not found");
+            bounds.push_back((uint32_t)found);
+            lower = (long long)found;
+            if (bounds.size() > N / s->bundle_keys + 2) return tec_fail(ctx, TEC_EHIP, "tec_sc_part1: epoch loop runaway");
+        }
+        const unsigned long long zero = 0;
+        SC_HIP(hipMemcpyAsync(d_found, &zero, 8, hipMemcpyHostToDevice, st));
+    }
+    s->n_epochs = (uint32_t)bounds.size() + 1;
+    SC_HIP(s->s_epoch.reserve(N));
+    if (bounds.empty()) {
+        SC_HIP(hipMemsetAsync(s->s_epoch.p, 0, N * 4, st));
+    } else {
+        SC_HIP(s->k32b.reserve(std::max<size_t>(N, bounds.size())));
+        SC_HIP(hipMemcpyAsync(s->k32b.p, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(epoch_assign_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->k32b.p, (uint32_t)bounds.size(),
+                           s->s_epoch.p);
+        SC_HIP(hipStreamSynchronize(st));
+    }
+    // ---- (epoch, key) instances, duplicates vs extra strings, per-barcode counts
+    SC_HIP(s->ihead.reserve(N));
+    SC_HIP(s->headidx.reserve(N));
+    SC_HIP(s->counted.reserve(N));
+    hipLaunchKernelGGL(ihead_kernel, dim3(g), dim3(kB), 0, st, N, s->ghead.p, s->s_epoch.p, s->ihead.p, s->k32a.p);
+    rc = scan_u32(ctx, s, s->k32a.p, s->headidx.p, N, true, rocprim::maximum<uint32_t>());
+    if (rc) return rc;
+    SC_HIP(s->cnt.reserve(s->n_wl));
+    SC_HIP(s->first_seen.reserve(s->n_wl));
+    SC_HIP(hipMemsetAsync(s->cnt.p, 0, (size_t)s->n_wl * 4, st));
+    SC_HIP(hipMemsetAsync(s->first_seen.p, 0xFF, (size_t)s->n_wl * 4, st));
+    hipLaunchKernelGGL(part1_count_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->headidx.p, s->s_klass.p, s->s_bcid.p,
+                       s->perm.p, s->counted.p, s->cnt.p, s->first_seen.p);
+    SC_HIP(hipGetLastError());
+    std::vector<uint32_t> hc(s->n_wl), hf(s->n_wl);
+    SC_HIP(hipMemcpyAsync(hc.data(), s->cnt.p, (size_t)s->n_wl * 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(hf.data(), s->first_seen.p, (size_t)s->n_wl * 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    for (uint32_t c = 0; c < s->n_wl; ++c)
+        if (hc[c]) {
+            s->cells_seen.push_back(c);
+            s->cells_count.push_back(hc[c]);
+            s->cells_first.push_back(hf[c]);
+        }
+    if (n_cells_seen) *n_cells_seen = s->cells_seen.size();
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_part1_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* count, uint64_t* first_seen) {
+    if (!ctx || !ctx->sc || !ctx->sc->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part1_fetch: run tec_sc_part1 first");
+    tec_sc_state* s = ctx->sc;
+    const size_t n = s->cells_seen.size();
+    if (n && bcid) memcpy(bcid, s->cells_seen.data(), n * 4);
+    if (n && count) memcpy(count, s->cells_count.data(), n * 8);
+    if (n && first_seen) memcpy(first_seen, s->cells_first.data(), n * 8);
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint64_t* kept_lines,
+                             uint64_t* n_cells_hit, uint64_t* n_coo) {
+    if (!ctx || !ctx->sc || !ctx->sc->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part23: run tec_sc_part1 first");
+    tec_sc_state* s = ctx->sc;
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    s->out_cell.clear(); s->out_hits.clear(); s->coo_cell.clear(); s->coo_name.clear(); s->coo_count.clear();
+    s->kept_lines = s->n_queries = s->n_assigned = 0;
+    if (kept_lines) *kept_lines = 0;
+    if (n_cells_hit) *n_cells_hit = 0;
+    if (n_coo) *n_coo = 0;
+    const uint64_t N = s->n_live;
+    if (N == 0 || n_selected == 0) return TEC_OK;
+    for (uint32_t i = 0; i < n_selected; ++i)
+        if (selected_bcid[i] >= s->n_wl || (i && selected_bcid[i] <= selected_bcid[i - 1]))
+            return tec_fail(ctx, TEC_EINVAL, "tec_sc_part23: selected barcodes must be ascending whitelist ids");
+    const unsigned g = grid_for(N);
+    // ---- selection mask and its exclusive prefix (number of selected ids below c)
+    dvec<uint32_t> sel, selprefix, lines, lkeys, lkeys2, lines2, firstkept, qflag, qscan, qrec, nemit, emoff, cellhits;
+    dvec<uint8_t> kept_rec;
+    dvec<uint64_t> keys, keys2, ukeys;
+    dvec<unsigned long long> scal;
+    auto cleanup = [&]() {
+        sel.release(); selprefix.release(); lines.release(); lkeys.release(); lkeys2.release(); lines2.release();
+        firstkept.release(); qflag.release(); qscan.release(); qrec.release(); nemit.release(); emoff.release();
+        cellhits.release(); kept_rec.release(); keys.release(); keys2.release(); ukeys.release(); scal.release();
+    };
+#define SC_TRY(call)                         \
+    do {                                     \
+        hipError_t e2__ = (call);            \
+        if (e2__ != hipSuccess) {            \
+            cleanup();                       \
+            return tec_fail(ctx, TEC_EHIP, "%s failed: %s", #call, hipGetErrorString(e2__)); \
+        }                                    \
+    } while (0)
+#define SC_RC(call)          \
+    do {                     \
+        int rc__ = (call);   \
+        if (rc__) {          \
+            cleanup();       \
+            return rc__;     \
+        }                    \
+    } while (0)
+    SC_TRY(sel.reserve(s->n_wl));
+    SC_TRY(selprefix.reserve(s->n_wl));
+    SC_TRY(hipMemsetAsync(sel.p, 0, (size_t)s->n_wl * 4, st));
+    SC_TRY(s->k32a.reserve(std::max<size_t>(N, n_selected)));
+    SC_TRY(hipMemcpyAsync(s->k32a.p, selected_bcid, (size_t)n_selected * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scatter_sel_kernel, dim3((n_selected + kB - 1) / kB), dim3(kB), 0, st, n_selected, s->k32a.p, sel.p);
+    SC_RC(scan_u32(ctx, s, sel.p, selprefix.p, s->n_wl, false, rocprim::plus<uint32_t>()));
+    // ---- bundle lines = instance heads in (epoch, barcode, UMI) order
+    SC_TRY(s->k32b.reserve(N));
+    hipLaunchKernelGGL(flag_from_u8_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->k32a.p);
+    SC_RC(scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, false, rocprim::plus<uint32_t>()));
+    uint32_t ls = 0, lf = 0;
+    SC_TRY(hipMemcpyAsync(&ls, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipMemcpyAsync(&lf, s->k32a.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipStreamSynchronize(st));
+    const uint64_t n_lines = (uint64_t)ls + lf;
+    SC_TRY(lines.reserve(n_lines));
+    hipLaunchKernelGGL(compact_idx_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p, lines.p);
+    if (s->n_epochs > 1) {
+        SC_TRY(lkeys.reserve(n_lines));
+        SC_TRY(lkeys2.reserve(n_lines));
+        SC_TRY(lines2.reserve(n_lines));
+        hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_epoch.p,
+                           lkeys.p);
+        SC_RC(sort_pairs(ctx, s, lkeys.p, lkeys2.p, lines.p, lines2.p, n_lines, 0, bits_for(s->n_epochs)));
+        std::swap(lines.p, lines2.p);
+        std::swap(lines.cap, lines2.cap);
+    }
+    // ---- drop rule, first kept line of a key across bundles
+    SC_TRY(kept_rec.reserve(N));
+    SC_TRY(firstkept.reserve((size_t)s->n_groups + 1));
+    SC_TRY(scal.reserve(4));
+    SC_TRY(hipMemsetAsync(kept_rec.p, 0, N, st));
+    SC_TRY(hipMemsetAsync(firstkept.p, 0xFF, ((size_t)s->n_groups + 1) * 4, st));
+    SC_TRY(hipMemsetAsync(scal.p, 0, 4 * 8, st));
+    hipLaunchKernelGGL(kept_kernel, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
+                       sel.p, selprefix.p, s->gid.p, kept_rec.p, firstkept.p, scal.p);
+    // ---- part 3 queries
+    SC_TRY(qflag.reserve(N));
+    SC_TRY(qscan.reserve(N));
+    hipLaunchKernelGGL(query_flag_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->counted.p, s->headidx.p, kept_rec.p,
+                       firstkept.p, s->gid.p, s->s_klass.p, qflag.p);
+    SC_RC(scan_u32(ctx, s, qflag.p, qscan.p, N, false, rocprim::plus<uint32_t>()));
+    uint32_t qs = 0, qf = 0;
+    SC_TRY(hipMemcpyAsync(&qs, qscan.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipMemcpyAsync(&qf, qflag.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    unsigned long long h_scal[4] = {0};
+    SC_TRY(hipMemcpyAsync(h_scal, scal.p, sizeof h_scal, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipStreamSynchronize(st));
+    s->kept_lines = h_scal[0];
+    if (kept_lines) *kept_lines = s->kept_lines;
+    const uint64_t nq = (uint64_t)qs + qf;
+    s->n_queries = nq;
+    if (nq == 0) {
+        cleanup();
+        return TEC_OK;
+    }
+    SC_TRY(qrec.reserve(nq));
+    hipLaunchKernelGGL(compact_idx_kernel, dim3(g), dim3(kB), 0, st, N, qflag.p, qscan.p, qrec.p);
+    SC_TRY(nemit.reserve(nq));
+    SC_TRY(emoff.reserve(nq));
+    SC_TRY(cellhits.reserve(s->n_wl));
+    SC_TRY(hipMemsetAsync(cellhits.p, 0, (size_t)s->n_wl * 4, st));
+    hipLaunchKernelGGL(sc_query_kernel<false>, dim3(grid_for(nq)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
+                       s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, nemit.p, (const uint32_t*)nullptr,
+                       (uint64_t*)nullptr, cellhits.p, s->stat.p, scal.p + 1);
+    SC_RC(scan_u32(ctx, s, nemit.p, emoff.p, nq, false, rocprim::plus<uint32_t>()));
+    uint32_t es = 0, ef = 0;
+    SC_TRY(hipMemcpyAsync(&es, emoff.p + (nq - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipMemcpyAsync(&ef, nemit.p + (nq - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipMemcpyAsync(h_scal, scal.p, sizeof h_scal, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipMemcpyAsync(s->h_stat, s->stat.p, sizeof s->h_stat, hipMemcpyDeviceToHost, st));
+    SC_TRY(hipStreamSynchronize(st));
+    s->n_assigned = h_scal[1];
+    if (s->h_stat[ST_NOSTRAND]) {
+        cleanup();
+        return tec_fail(ctx, TEC_ENOSTRAND, "a hit feature has no 'strand' (the reference raises KeyError, te_count.py:661)");
+    }
+    const uint64_t n_keys = (uint64_t)es + ef;
+    // per-cell hit counters (self.barcodes of part 3), ascending barcode id
+    {
+        std::vector<uint32_t> h(s->n_wl);
+        SC_TRY(hipMemcpy(h.data(), cellhits.p, (size_t)s->n_wl * 4, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < s->n_wl; ++c)
+            if (h[c]) {
+                s->out_cell.push_back(c);
+                s->out_hits.push_back(h[c]);
+            }
+    }
+    if (n_cells_hit) *n_cells_hit = s->out_cell.size();
+    if (n_keys) {
+        if (n_keys >= 0xFFFFFFF0ull) {
+            cleanup();
+            return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_part23: more than 2^32 (cell, feature) increments");
+        }
+        SC_TRY(keys.reserve(n_keys));
+        SC_TRY(keys2.reserve(n_keys));
+        hipLaunchKernelGGL(sc_query_kernel<true>, dim3(grid_for(nq)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
+                           s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, (uint32_t*)nullptr, emoff.p,
+                           keys.p, (uint32_t*)nullptr, s->stat.p, scal.p + 1);
+        hipLaunchKernelGGL(map_names_kernel, dim3(grid_for(n_keys)), dim3(kB), 0, st, n_keys, keys.p, ctx->d_int2ext);
+        size_t bytes = 0;
+        const unsigned kb = 32 + bits_for(s->n_wl);
+        SC_TRY(rocprim::radix_sort_keys(nullptr, bytes, keys.p, keys2.p, n_keys, 0, kb, st));
+        SC_TRY(s->tmp.reserve(bytes));
+        SC_TRY(rocprim::radix_sort_keys(s->tmp.p, bytes, keys.p, keys2.p, n_keys, 0, kb, st));
+        SC_TRY(ukeys.reserve(n_keys));
+        SC_TRY(nemit.reserve(n_keys));
+        bytes = 0;
+        SC_TRY(rocprim::run_length_encode(nullptr, bytes, keys2.p, (unsigned)n_keys, ukeys.p, nemit.p, scal.p + 2, st));
+        SC_TRY(s->tmp.reserve(bytes));
+        SC_TRY(rocprim::run_length_encode(s->tmp.p, bytes, keys2.p, (unsigned)n_keys, ukeys.p, nemit.p, scal.p + 2, st));
+        SC_TRY(hipMemcpyAsync(h_scal, scal.p, sizeof h_scal, hipMemcpyDeviceToHost, st));
+        SC_TRY(hipStreamSynchronize(st));
+        const size_t nu = (size_t)h_scal[2];
+        std::vector<uint64_t> hk(nu);
+        std::vector<uint32_t> hn(nu);
+        SC_TRY(hipMemcpy(hk.data(), ukeys.p, nu * 8, hipMemcpyDeviceToHost));
+        SC_TRY(hipMemcpy(hn.data(), nemit.p, nu * 4, hipMemcpyDeviceToHost));
+        s->coo_cell.resize(nu);
+        s->coo_name.resize(nu);
+        s->coo_count.resize(nu);
+        for (size_t i = 0; i < nu; ++i) {
+            s->coo_cell[i] = (uint32_t)(hk[i] >> 32);
+            s->coo_name[i] = (uint32_t)(hk[i] & 0xFFFFFFFFull);
+            s->coo_count[i] = hn[i];
+        }
+    }
+    if (n_coo) *n_coo = s->coo_cell.size();
+    cleanup();
+    return TEC_OK;
+#undef SC_TRY
+#undef SC_RC
+}
+
+extern "C" int tec_sc_fetch(tec_ctx* ctx, uint32_t* cell_bcid, uint64_t* cell_hits, uint32_t* coo_cell, uint32_t* coo_name,
+                            uint64_t* coo_count) {
+    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "tec_sc_fetch: no single-cell run");
+    tec_sc_state* s = ctx->sc;
+    if (!s->out_cell.empty()) {
+        if (cell_bcid) memcpy(cell_bcid, s->out_cell.data(), s->out_cell.size() * 4);
+        if (cell_hits) memcpy(cell_hits, s->out_hits.data(), s->out_hits.size() * 8);
+    }
+    if (!s->coo_cell.empty()) {
+        if (coo_cell) memcpy(coo_cell, s->coo_cell.data(), s->coo_cell.size() * 4);
+        if (coo_name) memcpy(coo_name, s->coo_name.data(), s->coo_name.size() * 4);
+        if (coo_count) memcpy(coo_count, s->coo_count.data(), s->coo_count.size() * 8);
+    }
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_stats(tec_ctx* ctx, tec_sc_stats_t* out) {
+    if (!ctx || !ctx->sc || !out) return tec_fail(ctx, TEC_ESTATE, "tec_sc_stats: no single-cell run");
+    tec_sc_state* s = ctx->sc;
+    out->records = s->n_seen;
+    out->qcfail = s->h_stat[ST_QCFAIL];
+    out->lowq = s->h_stat[ST_LOWQ];
+    out->invalid_barcode = s->h_stat[ST_BADBC];
+    out->skipped_chrom = s->h_stat[ST_SKIPCHROM];
+    out->survivors = s->n_live;
+    out->keys = s->n_groups;
+    out->bundles = s->n_live ? s->n_epochs : 0;
+    out->kept_lines = s->kept_lines;
+    out->assigned = s->n_assigned;
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_end(tec_ctx* ctx) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_sc_end: NULL context");
+    tec_sc_release(ctx);
+    return TEC_OK;
+}

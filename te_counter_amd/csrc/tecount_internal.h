@@ -44,6 +44,8 @@ struct tec_slot {  // one staged batch in HBM
     uint64_t ticket = 0;
 };
 
+struct tec_sc_state;
+
 struct tec_ctx {
     int device = 0;
     std::string err;
@@ -56,6 +58,10 @@ struct tec_ctx {
     void* d_index_blob = nullptr;
     uint64_t n_entries = 0, n_bins = 0, index_bytes = 0;
     std::vector<uint32_t> int2ext;  // internal (hotness-ordered) name id -> caller's name id
+    uint32_t* d_int2ext = nullptr;
+
+    // single cell
+    tec_sc_state* sc = nullptr;
 
     // bulk state
     bool bulk_open = false;
@@ -86,3 +92,5 @@ int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
 // bulk.hip
 int tec_bulk_init(tec_ctx* ctx);
 int tec_bulk_release(tec_ctx* ctx);
+// sc.hip
+void tec_sc_release(tec_ctx* ctx);

@@ -102,3 +102,60 @@ class Engine:
         ms, nl = C.c_double(), C.c_uint64()
         self._check(self._lib.tec_bulk_kernel_time(self._ctx, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    # ------------------------------------------------------------------ single cell
+    def sc_begin(self, stranded, mapq_min, whitelist24, bundle_keys, class_index_chrom, class_skip):
+        wl = np.ascontiguousarray(whitelist24, np.uint8)
+        cic = np.ascontiguousarray(class_index_chrom, np.int32)
+        csk = np.ascontiguousarray(class_skip, np.uint8)
+        self._check(self._lib.tec_sc_begin(self._ctx, int(bool(stranded)), int(mapq_min), wl.shape[0], _ptr(wl),
+                                           int(bundle_keys), len(cic), _ptr(cic), _ptr(csk)))
+
+    def sc_submit(self, cls, pos, end, flag, mapq, cb24, ub24, tagflags):
+        a = (np.ascontiguousarray(cls, np.int32), np.ascontiguousarray(pos, np.int32), np.ascontiguousarray(end, np.int32),
+             np.ascontiguousarray(flag, np.uint16), np.ascontiguousarray(mapq, np.uint8),
+             np.ascontiguousarray(cb24, np.uint8), np.ascontiguousarray(ub24, np.uint8),
+             np.ascontiguousarray(tagflags, np.uint8))
+        n = len(a[0])
+        if a[5].shape != (n, 24) or a[6].shape != (n, 24) or any(len(x) != n for x in a):
+            raise ValueError('single-cell batch arrays differ in length')
+        self._check(self._lib.tec_sc_submit(self._ctx, n, *[_ptr(x) for x in a]))
+
+    def sc_part1(self):
+        """-> (barcode ids ascending, raw counts, first-seen ordinals).  Raises AssertionError where
+        the reference asserts on a missing CB|CR / UB|UR tag (te_count.py:409, 426)."""
+        n = C.c_uint64()
+        rc = self._lib.tec_sc_part1(self._ctx, C.byref(n))
+        if rc == _lib.TEC_ENOCB:
+            raise AssertionError('CB or CR tag not found!')
+        if rc == _lib.TEC_ENOUB:
+            raise AssertionError('UB or UR tag not found!')
+        self._check(rc)
+        ids = np.zeros(n.value, np.uint32)
+        cnt = np.zeros(n.value, np.uint64)
+        first = np.zeros(n.value, np.uint64)
+        self._check(self._lib.tec_sc_part1_fetch(self._ctx, _ptr(ids), _ptr(cnt), _ptr(first)))
+        return ids, cnt, first
+
+    def sc_part23(self, selected_ids):
+        """-> dict(kept_lines, cells, cell_hits, coo_cell, coo_name, coo_count)."""
+        sel = np.ascontiguousarray(selected_ids, np.uint32)
+        kept, nc, nz = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = self._lib.tec_sc_part23(self._ctx, len(sel), _ptr(sel), C.byref(kept), C.byref(nc), C.byref(nz))
+        if rc == _lib.TEC_ENOSTRAND:
+            raise KeyError('strand')
+        self._check(rc)
+        out = {'kept_lines': kept.value, 'cells': np.zeros(nc.value, np.uint32), 'cell_hits': np.zeros(nc.value, np.uint64),
+               'coo_cell': np.zeros(nz.value, np.uint32), 'coo_name': np.zeros(nz.value, np.uint32),
+               'coo_count': np.zeros(nz.value, np.uint64)}
+        self._check(self._lib.tec_sc_fetch(self._ctx, _ptr(out['cells']), _ptr(out['cell_hits']), _ptr(out['coo_cell']),
+                                           _ptr(out['coo_name']), _ptr(out['coo_count'])))
+        return out
+
+    def sc_stats(self):
+        st = _lib.ScStats()
+        self._check(self._lib.tec_sc_stats(self._ctx, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in _lib.ScStats._fields_}
+
+    def sc_end(self):
+        self._check(self._lib.tec_sc_end(self._ctx))

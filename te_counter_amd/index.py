@@ -62,8 +62,8 @@ class FlatIndex:
             raise ValueError('feature arrays differ in length')
         if len(self.names) > (1 << _lib.META_NAME_BITS):
             raise ValueError('too many feature names')
-        if len(self.strands) > 8:
-            raise ValueError('more than 8 distinct strand strings')
+        if len(self.strands) > 7:
+            raise ValueError('more than 7 distinct strand strings')
         self._chrom_lookup = {k: i for i, k in enumerate(self.chrom_keys)}
 
     def __len__(self):
@@ -100,11 +100,11 @@ class FlatIndex:
                 if s is None:
                     s = strand_lookup[f['strand']] = len(strands)
                     strands.append(f['strand'])
-                    if s > 7:
-                        raise ValueError('more than 8 distinct strand strings')
+                    if s > 6:
+                        raise ValueError('more than 7 distinct strand strings')
             else:
                 has_strand = False
-                s = 0
+                s = _lib.STRAND_MISSING  # --sc: a hit on such a feature is a KeyError (te_count.py:661)
             chrom_id[i] = c
             left[i] = int(f['left'])  # location.py:31 stores int(left), int(right)
             right[i] = int(f['right'])

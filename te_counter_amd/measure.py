@@ -117,6 +117,118 @@ class measureTE:
         """te_count.py:42-165."""
         return self._bulk(filename, True, strand, log)
 
+    # ------------------------------------------------------------------ single cell
+    BUNDLE_KEYS = 10000000  # the spill threshold literal at te_count.py:377 -- a semantic constant
+    CELL_PAD = 1000         # te_count.py:502
+
+    def sc_parse_bamse(self, filename, UMIS=True, whitelistfilename=None, strand=False, log=None, label=None,
+                       maxcells=None):
+        """te_count.py:298-707.  Returns {ensg: {barcode: count}}; sets self.barcodes (barcode ->
+        number of UMIs that mapped to a feature, in the reference's insertion order) and
+        self.total_reads.  The reference's temporary bundle files are not written: the (CB,UB)
+        table lives in HBM."""
+        assert filename, 'You must specify a filename'
+        assert whitelistfilename, 'You must specify a whitelist of barcodes'
+        assert label, 'You must specify a label'
+        log = log or _NullLog()
+        if not os.path.exists(whitelistfilename):
+            raise AssertionError(f'{whitelistfilename} -w whitelist file not found')
+        with open(whitelistfilename, 'r') as fh:
+            whitelist = sorted(set(line.strip() for line in fh))  # te_count.py:330-339
+        self.barcodes = {}
+        src = self._open(filename)
+        q = self.quality_threshold
+        q_int = int(q) if isinstance(q, (int, np.integer)) else None
+        log.info('Part 1: Collapsing UMI/CB combinations')
+        self.load_genome()  # the reference loads it in part 3 (te_count.py:581); same index either way
+        eng = self._engine
+        skip, cls_of_tid, keys = _reads.chrom_class_table(src.reference_names)
+        key_skip = np.zeros(len(keys), np.uint8)
+        for t, c in enumerate(cls_of_tid):
+            key_skip[c] = skip[t]
+        key_chrom = np.array([self.genome._chrom_lookup.get(k, -1) for k in keys], np.int32)
+        n_records = 0
+        try:
+            eng.sc_begin(strand, q_int or 0, _reads.pack_whitelist(whitelist), self.BUNDLE_KEYS, key_chrom, key_skip)
+            for batch in src.batches(want_tags=True):
+                n_records += len(batch)
+                if q_int is None and self._reaches_mapq_test(batch, False):
+                    raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
+                arrays = _reads.sc_batch_arrays(batch, cls_of_tid)
+                if not UMIS:
+                    # --noumi: the UB|UR tags are never looked at and nothing is ever stored
+                    # (te_count.py:428-442); only the CB|CR assertion can still fire
+                    arrays = arrays[:7] + (arrays[7] | 2,)
+                eng.sc_submit(*arrays)
+            ids, counts, first = eng.sc_part1()
+        finally:
+            src.close()
+        self.total_reads = n_records + 1  # te_count.py:373,705
+        if not UMIS:
+            eng.sc_end()
+            raise ZeroDivisionError('division by zero')  # te_count.py:703: no UMI was ever stored
+
+        # ---- part 2 selection (te_count.py:502): best maxcells+1000 raw counts, ties first-seen first
+        log.info(f'Part 2: Get the best {maxcells} barcodes and remove dupes')
+        log.info(f'  Observed {len(ids):,} raw barcodes')
+        order = np.lexsort((first, -counts.astype(np.int64)))
+        selected = np.sort(ids[order[0:maxcells + self.CELL_PAD]])
+        out = eng.sc_part23(selected)
+        st = eng.sc_stats()
+        eng.sc_end()
+        self.stats = st
+        log.info(f"  Preserved {out['kept_lines']:,}/{self.total_reads:,} "
+                 f"({out['kept_lines'] / self.total_reads * 100:.1f}%) of the reads")
+        log.info('Part 3: Mapping the remaining UMIs to features')
+
+        names = self.all_feature_names
+        final_results = {n: {} for n in names}
+        for b, h in zip(out['cells'].tolist(), out['cell_hits'].tolist()):
+            self.barcodes[whitelist[b]] = h
+        cc, cn, cv = out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()
+        for c, n, v in zip(cc, cn, cv):
+            final_results[names[n]][whitelist[c]] = v
+        log.info('  In the total pipeling, processed {:,} SE reads'.format(self.total_reads))
+        log.info('  {:,} invalid barcode reads'.format(st['invalid_barcode']))
+        log.info('  {:,} Read quality is too low (<{})'.format(st['lowq'], self.quality_threshold))
+        log.info('  {:,} Reads QC failed'.format(st['qcfail']))
+        log.info('  {:,} total valid reads'.format(out['kept_lines']))
+        if out['kept_lines'] == 0:
+            raise ZeroDivisionError('division by zero')  # te_count.py:703
+        log.info('  Assigned {:,} ({:.1f}%) of total valid reads to features'.format(
+            st['assigned'], st['assigned'] / out['kept_lines'] * 100.0))
+        return final_results
+
+    def sc_save_result(self, result, out_filename, maxcells=None, log=None):
+        """te_count.py:709-754: `<out>.barcode_freq.tsv` and the dense cell x feature TSV."""
+        assert out_filename, 'You must specify a filename'
+        assert maxcells, 'You must specify maxcells'
+        log = log or _NullLog()
+        log.info('Densifying and saving "{0}"'.format(out_filename))
+        log.info('Found {0:,} barcodes'.format(len(self.barcodes)))
+        ranked = sorted(self.barcodes.items(), key=lambda kv: kv[1], reverse=True)  # stable, like itemgetter(1)
+        cells = [b for b, _ in ranked]
+        if len(self.barcodes) > maxcells:
+            log.info(f'Keeping the best {maxcells:,} barcodes')
+            cells = cells[0:maxcells]
+        elif maxcells > len(self.barcodes):
+            log.warning('Asked for {0:,} maxcells, but only {1:,} barcodes found'.format(maxcells, len(self.barcodes)))
+        if '.tsv' not in out_filename:
+            out_filename = f'{out_filename}.tsv'
+        freq_filename = out_filename.replace('.tsv', '.barcode_freq.tsv')
+        with open(freq_filename, 'w') as oh:
+            for b in cells:
+                oh.write('{0}\t{1}\n'.format(b, self.barcodes[b]))
+        log.info('Saving barcode read frequency file to {0}'.format(freq_filename))
+        features = list(result.keys())
+        with open(out_filename, 'w') as oh:
+            oh.write('{}\t{}\n'.format('name', '\t'.join(features)))
+            for b in cells:
+                row = [b]
+                for f in features:
+                    row.append(str(result[f].get(b, 0)))
+                oh.write('{}\n'.format('\t'.join(row)))
+
     def save_result_bulk(self, result, out_filename, log=None):
         """te_count.py:279-296: `name<TAB>count<TAB>CPM`, CPM = count / (total_reads / 1e6)."""
         assert out_filename, 'You must specify a filename'

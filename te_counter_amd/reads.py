@@ -146,3 +146,52 @@ def chrom_class_table(reference_names):
             keys.append(k)
         cls[i] = lookup[k]
     return skip, cls, keys
+
+
+TAG_BYTES = 24  # fixed width of the CB / UB fields handed to libtecount (include/tecount.h)
+
+
+def pack_tags(values, what):
+    """list of str|None -> (uint8[n,24] zero padded, present bool[n], too_long bool[n])."""
+    n = len(values)
+    out = np.zeros((n, TAG_BYTES), np.uint8)
+    present = np.zeros(n, bool)
+    too_long = np.zeros(n, bool)
+    for i, v in enumerate(values):
+        if v is None:
+            continue
+        present[i] = True
+        b = v.encode('utf-8') if isinstance(v, str) else bytes(v)
+        if len(b) > TAG_BYTES:
+            too_long[i] = True
+            continue
+        out[i, :len(b)] = np.frombuffer(b, np.uint8)
+    return out, present, too_long
+
+
+def pack_whitelist(sorted_barcodes):
+    """sorted(set(whitelist lines)) -> uint8[n,24]; the row number is the barcode id
+    (te_count.py:338).  Python's str order equals bytewise order of the UTF-8 encoding."""
+    n = len(sorted_barcodes)
+    out = np.zeros((n, TAG_BYTES), np.uint8)
+    for i, v in enumerate(sorted_barcodes):
+        b = v.encode('utf-8')
+        if len(b) > TAG_BYTES or b'\0' in b:
+            raise ValueError('whitelist barcode %r is longer than %d bytes' % (v, TAG_BYTES))
+        out[i, :len(b)] = np.frombuffer(b, np.uint8)
+    return out
+
+
+def sc_batch_arrays(batch, tid_class):
+    """RecordBatch -> the arrays tec_sc_submit takes."""
+    n = len(batch)
+    if batch.cb is None or batch.ub is None:
+        raise ValueError('this alignment source does not carry CB/UB tags')
+    cb, cb_present, cb_long = pack_tags(batch.cb, 'CB')
+    ub, ub_present, ub_long = pack_tags(batch.ub, 'UB')
+    if ub_long.any():
+        raise ValueError('UMI longer than %d bytes is not supported' % TAG_BYTES)
+    tagflags = (cb_present.astype(np.uint8) | (ub_present.astype(np.uint8) << 1) | (cb_long.astype(np.uint8) << 2))
+    cls = np.where(batch.tid >= 0, tid_class[np.clip(batch.tid, 0, max(0, len(tid_class) - 1))], -1).astype(np.int32) \
+        if len(tid_class) else np.full(n, -1, np.int32)
+    return cls, batch.pos, batch.end, batch.flag, batch.mapq, cb, ub, tagflags

@@ -1,0 +1,69 @@
+"""GPU parity for the single-cell path: measureTE.sc_parse_bamse / sc_save_result on the MI355X
+against the golden vectors captured from the reference, and against the Python oracle on
+seeded inputs (several bundle thresholds, binding cell selection, ragged batches)."""
+
+import pytest
+
+import datagen as dg
+from conftest import golden_names, load_golden
+from helpers import flat_from_golden
+from oracle import te_oracle as orc
+from te_counter_amd import FlatIndex, measureTE
+from te_counter_amd.reads import ListSource
+
+pytestmark = pytest.mark.gpu
+
+SC = [n for n in golden_names('sc_') if '_err_' not in n]
+
+
+def run_sc(flat, records, whitelist, maxcells, strand, q, bundle_keys, tmp_path, batch_size=997, umis=True):
+    wl = tmp_path / 'wl.txt'
+    wl.write_text(''.join(b + '\n' for b in whitelist))
+    m = measureTE('test', q)
+    m.BUNDLE_KEYS = bundle_keys
+    m.bind_genome(flat)
+    res = m.sc_parse_bamse(ListSource(records, batch_size=batch_size), UMIS=umis, whitelistfilename=str(wl),
+                           strand=strand, label='lab', maxcells=maxcells)
+    out = str(tmp_path / 'o.tsv')
+    m.sc_save_result(res, out, maxcells=maxcells)
+    return m, res, open(out).read(), open(out.replace('.tsv', '.barcode_freq.tsv')).read()
+
+
+@pytest.mark.parametrize('name', SC)
+def test_golden(name, tmp_path):
+    g = load_golden(name)
+    p = g['params']
+    m, res, tsv, freq = run_sc(flat_from_golden(g), g['records'], g['whitelist'], p['maxcells'], p['strand'], p['q'],
+                               p['bundle_threshold'], tmp_path)
+    assert m.total_reads == g['expected']['total_reads']
+    assert [list(kv) for kv in m.barcodes.items()] == g['expected']['barcodes']
+    assert res == g['expected']['result']
+    assert tsv == g['expected']['tsv']
+    assert freq == g['expected']['barcode_freq']
+
+
+@pytest.mark.parametrize('name,exc', [('sc_err_no_strand_key', KeyError), ('sc_err_noumi', ZeroDivisionError),
+                                      ('sc_err_no_cb', AssertionError), ('sc_err_no_ub', AssertionError)])
+def test_failure_modes(name, exc, tmp_path):
+    g = load_golden(name)
+    assert g['expected']['exception'] == exc.__name__
+    p = g['params']
+    with pytest.raises(exc):
+        run_sc(flat_from_golden(g), g['records'], p['whitelist'], p['maxcells'], p['strand'], 20, 10 ** 7, tmp_path,
+               umis=p.get('umis', True))
+
+
+@pytest.mark.parametrize('seed', [41, 42])
+@pytest.mark.parametrize('strand', [False, True])
+@pytest.mark.parametrize('thr', [10 ** 7, 700, 97])
+def test_random_vs_oracle(seed, strand, thr, tmp_path):
+    types = ['protein_coding', 'lncRNA', 'TE', 'TE', 'snRNA', 'enhancer', 'miRNA']
+    feats = dg.make_features(seed, 1500, span=300000, types=types)
+    wl = dg.make_whitelist(seed, 400)
+    recs = dg.make_sc_records(seed + 1, 20000, wl, feats, span=300000, n_cells=60)
+    want_res, want_bc, want_total = orc.sc_count(feats, recs, wl, 25, strand=strand, bundle_threshold=thr)
+    m, res, tsv, freq = run_sc(FlatIndex.from_features(feats), recs, wl, 25, strand, 20, thr, tmp_path, batch_size=4093)
+    assert m.total_reads == want_total
+    assert list(m.barcodes.items()) == list(want_bc.items())
+    assert res == want_res
+    assert (tsv, freq) == orc.format_sc_tsv(want_res, want_bc, 25)
