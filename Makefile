@@ -9,7 +9,7 @@ all: $(LIB) oracle
 
 $(LIB): $(CSRC) $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-result \
-	    -Iinclude -o $@ $(CSRC)
+	    -Iinclude -o $@ $(CSRC) -lz -lpthread
 
 oracle:
 	$(MAKE) -C oracle

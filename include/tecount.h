@@ -204,6 +204,31 @@ int tec_sc_fetch(tec_ctx* ctx, uint32_t* cell_bcid, uint64_t* cell_hits, uint32_
 int tec_sc_stats(tec_ctx* ctx, tec_sc_stats_t* out);
 int tec_sc_end(tec_ctx* ctx);
 
+/* ---- Alignment decoding (the step before the path) ------------------------------------------
+ * Replaces pysam.AlignmentFile(filename, 'r') / next(sam) and the AlignedSegment attributes the
+ * reference reads (te_count.py:65,78-98 / 190,203-214 / 351,393-438).  pysam (htslib) is a
+ * third-party dependency that is not part of the reference tree and is not pinned there; this
+ * decoder follows the SAM/BAM specification.  BGZF-compressed BAM and plain-text SAM are both
+ * accepted (pysam's 'r' mode auto-detects as well).
+ *
+ * tec_bam_read fills up to max_records rows: tid (-1 = '*'), pos = reference_start (0-based),
+ * end = reference_end (pos + reference-consuming CIGAR length; INT32_MIN when the record has no
+ * CIGAR, where pysam returns None), flag, mapq, and optionally
+ *   qkey      a 64-bit hash of '_'.join(qname.split('/')[0:-1]), the string the PE path compares
+ *             between mates (te_count.py:92)
+ *   cb24/ub24 the CB (else CR) / UB (else UR) 'Z' tag values, zero padded to 24 bytes
+ *   tagflags  bit 0 CB|CR present, bit 1 UB|UR present, bit 2 barcode > 24 bytes, bit 3 UMI > 24 bytes
+ * *n_out < max_records means end of file.
+ */
+typedef struct tec_bam tec_bam;
+int tec_bam_open(const char* path, int n_threads, tec_bam** out);
+void tec_bam_close(tec_bam* r);
+const char* tec_bam_last_error(const tec_bam* r);
+int tec_bam_n_refs(const tec_bam* r);
+const char* tec_bam_ref_name(const tec_bam* r, int i);
+int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int32_t* pos, int32_t* end, uint16_t* flag,
+                 uint8_t* mapq, uint64_t* qkey, uint8_t* cb24, uint8_t* ub24, uint8_t* tagflags, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

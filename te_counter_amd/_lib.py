@@ -63,6 +63,12 @@ _SIGNATURES = {
     'tec_sc_fetch': (C.c_int, [_p, _p, _p, _p, _p, _p]),
     'tec_sc_stats': (C.c_int, [_p, C.POINTER(ScStats)]),
     'tec_sc_end': (C.c_int, [_p]),
+    'tec_bam_open': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_p)]),
+    'tec_bam_close': (None, [_p]),
+    'tec_bam_last_error': (C.c_char_p, [_p]),
+    'tec_bam_n_refs': (C.c_int, [_p]),
+    'tec_bam_ref_name': (C.c_char_p, [_p, C.c_int]),
+    'tec_bam_read': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_u64)]),
 }
 
 _lib = None

@@ -9,8 +9,10 @@ closed form, see csrc/bulk.hip).
 Own file format (`.tecidx`):  magic, JSON header, 64-byte aligned raw little-endian arrays.
 """
 
+import io
 import json
 import os
+import pickle
 
 import numpy as np
 
@@ -113,6 +115,29 @@ class FlatIndex:
             raise ValueError('feature coordinates outside the supported int32 range [0, 2^31-2)')
         return cls(names, chrom_keys, strands, chrom_id, left, right, meta, has_strand)
 
+    @classmethod
+    def from_glb(cls, path):
+        """Import an index built by the reference's te_genome: a `.glb` is a pickle of the whole
+        genelist object (te_count/miniglbase/base_genelist.py:302-305, utils.py:21-59).  Only
+        `linearData` is read, through a restricted unpickler that maps the reference's classes
+        (te_count.miniglbase.genelist.genelist, ...location.location) to inert stand-ins -- no
+        reference code is imported or executed."""
+        with open(path, 'rb') as fh:
+            obj = _GlbUnpickler(io.BytesIO(fh.read())).load()
+        rows = getattr(obj, 'linearData', None)
+        if rows is None:
+            raise ValueError('%s holds no linearData' % path)
+        feats = []
+        for r in rows:
+            loc = r['loc']
+            d = loc.loc if hasattr(loc, 'loc') else loc
+            f = {'chr': d['chr'], 'left': d['left'], 'right': d['right'], 'name': r.get('name'), 'type': r['type'],
+                 'ensg': r['ensg']}
+            if 'strand' in r:
+                f['strand'] = r['strand']
+            feats.append(f)
+        return cls.from_features(feats)
+
     # ------------------------------------------------------------------ queries the host needs
     def chrom_id_of_read(self, reference_name):
         """-1 unless reference_name.replace('chr','') is an index key (te_count.py:96-102)."""
@@ -157,3 +182,34 @@ class FlatIndex:
         names = blob.split('\n') if header['n_names'] else []
         return cls(names, header['chrom_keys'], header['strands'], out[0], out[1], out[2], out[3],
                    header.get('has_strand', True))
+
+
+class _GlbStub:
+    """Inert stand-in for any class of the reference's miniglbase package found in a .glb."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        elif isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):
+            self.__dict__.update(state[1] or {})
+            if isinstance(state[0], dict):
+                self.__dict__.update(state[0])
+
+
+class _GlbUnpickler(pickle.Unpickler):
+    _SAFE = {('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'list'), ('builtins', 'dict'),
+             ('builtins', 'tuple'), ('builtins', 'object'), ('collections', 'OrderedDict'),
+             ('collections', 'defaultdict'), ('copyreg', '_reconstructor')}
+
+    def find_class(self, module, name):
+        if module.startswith('te_count.miniglbase') or module.startswith('glbase3') or module.startswith('miniglbase'):
+            return _GlbStub
+        if (module, name) in self._SAFE:
+            import importlib
+            return getattr(importlib.import_module(module), name)
+        if module == 'logging' or module.startswith('numpy'):
+            return _GlbStub
+        raise pickle.UnpicklingError('refusing to load %s.%s from a .glb' % (module, name))

@@ -11,6 +11,7 @@ import os
 import numpy as np
 
 from . import reads as _reads
+from .bam import NO_END
 from .engine import Engine
 from .index import FlatIndex
 
@@ -23,7 +24,7 @@ class _NullLog:
 
 
 class measureTE:
-    def __init__(self, base_path, quality_threshold, device=0, batch_size=1 << 22, bin_shift=0):
+    def __init__(self, base_path, quality_threshold, device=0, batch_size=1 << 22, bin_shift=0, world=None):
         self.base_path = base_path
         self.total_reads = 0
         self.quality_threshold = quality_threshold
@@ -33,6 +34,10 @@ class measureTE:
         self.genome = None
         self.stats = {}
         self._engine = None
+        if world is None:
+            from .dist import World
+            world = World()
+        self.world = world  # rank / size of the multi-GPU job (1 process per GPU)
 
     # ------------------------------------------------------------------ index
     def bind_genome(self, genelist_glb_filename):
@@ -47,7 +52,12 @@ class measureTE:
         """te_count.py:31-35: loads the index and derives all_feature_names."""
         assert getattr(self, 'genelist_glb_filename', None) is not None, 'You need to bind the genome first'
         src = self.genelist_glb_filename
-        self.genome = src if isinstance(src, FlatIndex) else FlatIndex.load(src)
+        if isinstance(src, FlatIndex):
+            self.genome = src
+        elif str(src).endswith('.glb'):
+            self.genome = FlatIndex.from_glb(src)  # an index built by the reference's te_genome
+        else:
+            self.genome = FlatIndex.load(src)
         self.all_feature_names = list(self.genome.names)
         if self._engine is None:
             self._engine = Engine(self.device)
@@ -75,7 +85,7 @@ class measureTE:
         pairs = _reads.PairAssembler(tid_map, q_int or 0) if paired else None
         try:
             eng.bulk_begin(q_int or 0)
-            for batch in src.batches():
+            for ordinal, batch in enumerate(src.batches()):
                 n_records += len(batch)
                 if q_int is None and self._reaches_mapq_test(batch, paired):
                     # `-q N` on the reference CLI hands over a list and the first record that
@@ -83,9 +93,15 @@ class measureTE:
                     # te_count.py:88,208)
                     raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
                 units = pairs.units(batch) if paired else _reads.se_units(batch, tid_map)
-                if len(units[0]):
+                if not paired and (units[2] == NO_END).any():
+                    self._check_reference_end(units, q_int or 0)
+                if len(units[0]) and self.world.mine(ordinal):
                     eng.bulk_submit(*units)
             counts, stats = eng.bulk_finish()
+            if self.world.size > 1:  # RCCL sum-reduce of the per-GPU count vectors
+                keys = ('units', 'assigned', 'lowq', 'badchrom', 'qcfail')
+                counts, sv = self.world.sum_counts(counts, [stats[k] for k in keys])
+                stats = {k: int(v) for k, v in zip(keys, sv)}
         finally:
             src.close()
         units_total = n_records // 2 if paired else n_records
@@ -98,6 +114,14 @@ class measureTE:
         log.info('{:,} Reads mapped to an invalid chromosome'.format(stats['badchrom']))
         log.info('{:,} Reads are QC fails'.format(stats['qcfail']))
         return {name: int(c) for name, c in zip(self.all_feature_names, counts)}
+
+    @staticmethod
+    def _check_reference_end(units, q):
+        # a mapped SE record without CIGAR has reference_end None: `loc2+1` dies (te_count.py:223)
+        chrom, _, p2, flag, mapq = units
+        bad = (p2 == NO_END) & ((flag & _reads.FLAG_FILTER) == 0) & (mapq >= q) & (chrom >= 0)
+        if bad.any():
+            raise TypeError("unsupported operand type(s) for +: 'NoneType' and 'int'")
 
     @staticmethod
     def _reaches_mapq_test(batch, paired):

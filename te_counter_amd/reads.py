@@ -15,7 +15,7 @@ FLAG_FILTER = 0x4 | 0x200 | 0x400
 
 class RecordBatch:
     """tid/pos/end/flag/mapq arrays (+ optional qname list, cb/ub object arrays for --sc)."""
-    __slots__ = ('tid', 'pos', 'end', 'flag', 'mapq', 'qname', 'cb', 'ub')
+    __slots__ = ('tid', 'pos', 'end', 'flag', 'mapq', 'qname', 'cb', 'ub', 'qkey', 'cb24', 'ub24', 'tagflags')
 
     def __init__(self, tid, pos, end, flag, mapq, qname=None, cb=None, ub=None):
         self.tid = np.ascontiguousarray(tid, np.int32)
@@ -26,6 +26,8 @@ class RecordBatch:
         self.qname = qname
         self.cb = cb
         self.ub = ub
+        self.qkey = None      # native decoder: hash of the mate-name key (te_count.py:92)
+        self.cb24 = self.ub24 = self.tagflags = None  # native decoder: tags already packed
 
     def __len__(self):
         return len(self.tid)
@@ -97,6 +99,8 @@ class PairAssembler:
     def units(self, batch):
         tid, pos, flag, mapq = batch.tid, batch.pos, batch.flag, batch.mapq
         qn = batch.qname
+        if qn is None and batch.qkey is not None:
+            qn = batch.qkey  # hashes compare like the strings do
         if self._carry is not None:
             c = self._carry
             tid = np.concatenate([[c[0]], tid]).astype(np.int32)
@@ -104,7 +108,7 @@ class PairAssembler:
             flag = np.concatenate([[c[2]], flag]).astype(np.uint16)
             mapq = np.concatenate([[c[3]], mapq]).astype(np.uint8)
             if qn is not None:
-                qn = [c[4]] + list(qn)
+                qn = np.concatenate([[c[4]], qn]) if isinstance(qn, np.ndarray) else [c[4]] + list(qn)
             self._carry = None
         n = len(tid)
         if n % 2:
@@ -123,9 +127,13 @@ class PairAssembler:
     def _check_names(self, qn, n, fl, mq):
         # The reference compares mate names only for pairs that passed the flag and mapq filters
         # (te_count.py:81-94) and dies on a mismatch (sys.quit does not exist -> AttributeError).
+        live = ((fl & FLAG_FILTER) == 0) & (mq.astype(np.int64) >= self.q)
+        if isinstance(qn, np.ndarray):
+            if (live & (qn[0:n:2] != qn[1:n:2])).any():
+                raise AttributeError("module 'sys' has no attribute 'quit'")
+            return
         if not any('/' in q for q in qn[:n]):
             return  # names without '/' always compare '' == ''
-        live = ((fl & FLAG_FILTER) == 0) & (mq.astype(np.int64) >= self.q)
         for k in np.nonzero(live)[0]:
             if _mate_key(qn[2 * k]) != _mate_key(qn[2 * k + 1]):
                 raise AttributeError("module 'sys' has no attribute 'quit'")
@@ -185,13 +193,18 @@ def pack_whitelist(sorted_barcodes):
 def sc_batch_arrays(batch, tid_class):
     """RecordBatch -> the arrays tec_sc_submit takes."""
     n = len(batch)
-    if batch.cb is None or batch.ub is None:
-        raise ValueError('this alignment source does not carry CB/UB tags')
-    cb, cb_present, cb_long = pack_tags(batch.cb, 'CB')
-    ub, ub_present, ub_long = pack_tags(batch.ub, 'UB')
-    if ub_long.any():
-        raise ValueError('UMI longer than %d bytes is not supported' % TAG_BYTES)
-    tagflags = (cb_present.astype(np.uint8) | (ub_present.astype(np.uint8) << 1) | (cb_long.astype(np.uint8) << 2))
+    if batch.tagflags is not None:
+        cb, ub, tagflags = batch.cb24, batch.ub24, batch.tagflags
+        if (tagflags & 8).any():
+            raise ValueError('UMI longer than %d bytes is not supported' % TAG_BYTES)
+    else:
+        if batch.cb is None or batch.ub is None:
+            raise ValueError('this alignment source does not carry CB/UB tags')
+        cb, cb_present, cb_long = pack_tags(batch.cb, 'CB')
+        ub, ub_present, ub_long = pack_tags(batch.ub, 'UB')
+        if ub_long.any():
+            raise ValueError('UMI longer than %d bytes is not supported' % TAG_BYTES)
+        tagflags = (cb_present.astype(np.uint8) | (ub_present.astype(np.uint8) << 1) | (cb_long.astype(np.uint8) << 2))
     cls = np.where(batch.tid >= 0, tid_class[np.clip(batch.tid, 0, max(0, len(tid_class) - 1))], -1).astype(np.int32) \
         if len(tid_class) else np.full(n, -1, np.int32)
     return cls, batch.pos, batch.end, batch.flag, batch.mapq, cb, ub, tagflags

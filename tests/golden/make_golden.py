@@ -163,5 +163,12 @@ def main():
                lambda: rh.run_sc(feats, noub, wl, 5))
 
 
+    # an index file written by the reference itself (a pickle): fixture for the .glb importer
+    feats = dg.make_features(9, 200)
+    rh.build_reference_index(feats, os.path.join(HERE, 'ref_built_index.glb'))
+    with gzip.open(os.path.join(HERE, 'ref_built_index.features.json.gz'), 'wt') as fh:
+        json.dump(feats, fh)
+
+
 if __name__ == '__main__':
     main()

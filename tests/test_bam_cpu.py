@@ -1,0 +1,107 @@
+"""The native BGZF/BAM/SAM decoder (csrc/bamio.hip, host code) against files written by
+te_counter_amd.bam.write_bam / write_sam -- runs without a GPU."""
+
+import numpy as np
+import pytest
+
+import datagen as dg
+from te_counter_amd import bam
+from te_counter_amd.reads import ListSource, PairAssembler, sc_batch_arrays, chrom_class_table, se_units
+
+
+def _records(n, seed=3, sc=False):
+    if sc:
+        wl = dg.make_whitelist(seed, 50)
+        recs = dg.make_sc_records(seed, n, wl, None, n_cells=8)
+    else:
+        recs = dg.make_records(seed, n, paired=True)
+    for i, r in enumerate(recs):
+        if i % 97 == 0 and not sc:
+            r['end'] = r['pos']  # no CIGAR -> reference_end is None in pysam
+    return recs
+
+
+def _refs(recs):
+    return ListSource(recs).reference_names
+
+
+def _collect(src, want_tags=False):
+    out = []
+    for b in src.batches(want_tags=want_tags):
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize('writer,ext', [(bam.write_bam, 'bam'), (bam.write_sam, 'sam')])
+@pytest.mark.parametrize('batch', [1, 7, 1000, 1 << 20])
+def test_roundtrip_fields(tmp_path, writer, ext, batch):
+    recs = _records(5000)
+    refs = _refs(recs)
+    path = str(tmp_path / ('x.' + ext))
+    writer(path, refs, recs)
+    src = bam.open_alignment(path, batch_size=batch, threads=3)
+    assert src.reference_names == refs
+    got = _collect(src)
+    src.close()
+    tid = np.concatenate([b.tid for b in got])
+    assert len(tid) == len(recs)
+    assert [refs[t] if t >= 0 else None for t in tid] == [r['rname'] for r in recs]
+    assert np.array_equal(np.concatenate([b.pos for b in got]), [r['pos'] for r in recs])
+    want_end = [r['end'] if r['end'] > r['pos'] else bam.NO_END for r in recs]
+    assert np.array_equal(np.concatenate([b.end for b in got]), want_end)
+    assert np.array_equal(np.concatenate([b.flag for b in got]), [r['flag'] for r in recs])
+    assert np.array_equal(np.concatenate([b.mapq for b in got]), [r['mapq'] for r in recs])
+    qk = np.concatenate([b.qkey for b in got])
+    assert len(set(qk.tolist())) == 1  # names without '/' all reduce to the empty key
+
+
+def test_units_match_list_source(tmp_path):
+    """SE and PE units from the decoded BAM == units from the in-memory records."""
+    recs = [r for r in _records(4001) if r['end'] > r['pos']]
+    refs = _refs(recs)
+    path = str(tmp_path / 'x.bam')
+    bam.write_bam(path, refs, recs)
+    tid_map = np.arange(len(refs), dtype=np.int32)
+    for paired in (False, True):
+        outs = []
+        for src in (bam.open_alignment(path, batch_size=333), ListSource(recs, batch_size=1000)):
+            pa = PairAssembler(tid_map, 20)
+            parts = [pa.units(b) if paired else se_units(b, tid_map) for b in src.batches()]
+            outs.append([np.concatenate([p[i] for p in parts]) for i in range(5)])
+            src.close()
+        assert all(np.array_equal(a, b) for a, b in zip(*outs))
+
+
+def test_mate_name_keys(tmp_path):
+    recs = [{'flag': 0, 'mapq': 255, 'qname': q, 'rname': 'chr1', 'pos': 5, 'end': 50}
+            for q in ('a/1', 'a/2', 'x/y/1', 'x_y/2', 'b/1', 'c/1', 'plain', 'other')]
+    path = str(tmp_path / 'n.bam')
+    bam.write_bam(path, ['chr1'], recs)
+    qk = _collect(bam.open_alignment(path))[0].qkey
+    assert qk[0] == qk[1] and qk[2] == qk[3] and qk[4] != qk[5] and qk[6] == qk[7]
+    with pytest.raises(AttributeError):
+        PairAssembler(np.zeros(1, np.int32), 20).units(_collect(bam.open_alignment(path))[0])
+
+
+@pytest.mark.parametrize('writer,ext', [(bam.write_bam, 'bam'), (bam.write_sam, 'sam')])
+def test_sc_tags(tmp_path, writer, ext):
+    recs = _records(3000, sc=True)
+    recs[5]['tags'] = {}
+    recs[6]['tags'] = {'CB': 'A' * 30, 'UB': 'ACGT'}
+    recs[7]['tags'] = {'CR': 'ACGTACGT', 'UR': 'TTTT', 'NH': 'x'}
+    refs = _refs(recs)
+    path = str(tmp_path / ('s.' + ext))
+    writer(path, refs, recs)
+    _, cls, _ = chrom_class_table(refs)
+    a = [np.concatenate(x) for x in zip(*[sc_batch_arrays(b, cls) for b in bam.open_alignment(path, 701).batches(True)])]
+    b = [np.concatenate(x) for x in zip(*[sc_batch_arrays(b, cls) for b in ListSource(recs, 500).batches(True)])]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[7][5] == 0 and a[7][6] == (1 | 2 | 4) and a[7][7] == 3
+
+
+def test_not_a_bam(tmp_path):
+    p = tmp_path / 'junk.bam'
+    p.write_bytes(b'\x1f\x8b' + b'junkjunkjunkjunkjunkjunk')
+    with pytest.raises(IOError):
+        bam.open_alignment(str(p))

@@ -92,3 +92,24 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.tec_version() == 100
+
+
+def test_glb_import_of_a_reference_built_index():
+    """tests/golden/ref_built_index.glb was written by the reference's genelist.save()."""
+    import gzip
+    import json
+    from conftest import GOLDEN_DIR
+    feats = json.load(gzip.open(os.path.join(GOLDEN_DIR, 'ref_built_index.features.json.gz'), 'rt'))
+    a = FlatIndex.from_glb(os.path.join(GOLDEN_DIR, 'ref_built_index.glb'))
+    b = FlatIndex.from_features(feats)
+    assert a.names == b.names and a.chrom_keys == b.chrom_keys and a.strands == b.strands
+    for k in ('chrom_id', 'left', 'right', 'meta'):
+        assert np.array_equal(getattr(a, k), getattr(b, k))
+
+
+def test_glb_import_refuses_foreign_classes(tmp_path):
+    import pickle
+    p = tmp_path / 'evil.glb'
+    p.write_bytes(pickle.dumps(os.system))
+    with pytest.raises(pickle.UnpicklingError):
+        FlatIndex.from_glb(str(p))
