@@ -61,11 +61,35 @@ struct Sink {
     uint32_t* lds;
     uint32_t k_lds;
     unsigned long long* counts;
-    __device__ __forceinline__ void add(uint32_t name) const {
+    bool aggregate;  // coordinate-sorted batches: neighbouring lanes hit the same name
+    __device__ __forceinline__ void add_n(uint32_t name, uint32_t n) const {
         if (name < k_lds)
-            atomicAdd(&lds[name >> 1], 1u << ((name & 1u) * 16u));
+            atomicAdd(&lds[name >> 1], n << ((name & 1u) * 16u));
         else
-            atomicAdd(&counts[name], 1ull);
+            atomicAdd(&counts[name], (unsigned long long)n);
+    }
+    // Runs of equal names over the lanes that are adding right now are folded into one add by the
+    // run's first lane (64 lanes on one LDS word would serialise otherwise).  n <= 64 per add.
+    __device__ __forceinline__ void add_runs(uint32_t name) const {
+        const unsigned long long active = __ballot(1);
+        const unsigned lane = threadIdx.x & 63u;
+        const unsigned long long below = active & ((1ull << lane) - 1ull);
+        const int prev = below ? 63 - __builtin_clzll(below) : (int)lane;
+        const uint32_t pn = (uint32_t)__builtin_amdgcn_ds_bpermute(prev << 2, (int)name);
+        const bool head = !below || pn != name;
+        const unsigned long long heads = __ballot(head);
+        if (head) {
+            const unsigned long long above = lane == 63u ? 0ull : (heads >> (lane + 1u)) << (lane + 1u);
+            const unsigned next = above ? (unsigned)__builtin_ctzll(above) : 64u;
+            const unsigned long long upto = next == 64u ? ~0ull : ((1ull << next) - 1ull);
+            add_n(name, (uint32_t)__builtin_popcountll(active & upto & ~((1ull << lane) - 1ull)));
+        }
+    }
+    __device__ __forceinline__ void add(uint32_t name) const {
+        if (aggregate)
+            add_runs(name);
+        else
+            add_n(name, 1u);
     }
 };
 
@@ -147,17 +171,21 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
                                                            const uint16_t* __restrict__ flag,
                                                            const uint8_t* __restrict__ mapq, uint64_t n, int mapq_min,
                                                            unsigned long long* counts, unsigned long long* stats,
-                                                           uint32_t k_lds) {
+                                                           uint32_t k_lds, uint64_t span, uint32_t flags) {
     extern __shared__ uint32_t hist[];
     constexpr uint32_t chunk = U * kBlock;
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     __syncthreads();
-    const Sink sink{hist, k_lds, counts};
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0};
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     uint32_t since_flush = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
+    // A workgroup owns spans of consecutive chunks, `gridDim.x` spans apart: at any moment the
+    // workgroups are spread over the batch (for coordinate-sorted input: over the genome, so
+    // that they do not all pull the same index lines through one L2 channel).
+    for (uint64_t s0 = (uint64_t)blockIdx.x * span; s0 < n; s0 += (uint64_t)gridDim.x * span)
+    for (uint64_t base = s0; base < n && base < s0 + span; base += chunk) {
         if (since_flush + chunk > 65535u) {  // a 16-bit counter gains at most 1 per unit
             flush_hist(hist, words, counts);
             since_flush = 0;
@@ -267,7 +295,8 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
 }
 
 typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
-                               const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t);
+                               const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t,
+                               uint64_t, uint32_t);
 
 template <int U>
 count_kernel_t pick_mixed(bool mixed) {
@@ -337,9 +366,13 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, kLdsBytes / 2);
     const size_t lds = (size_t)((k_lds + 1) / 2) * 4;
+    // spans: ~span_div per workgroup, each a whole number of chunks
+    uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
+    if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
     hipLaunchKernelGGL(pick_kernel(mixed, unroll), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
-                       u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds);
+                       u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
+                       (uint32_t)ctx->aggregate);
     TEC_HIP(ctx, hipGetLastError());
     TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
     ++ctx->kernel_launches;
@@ -357,6 +390,10 @@ int tec_bulk_init(tec_ctx* ctx) {
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4 || u == 8) ? u : 2;
+    e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
+    ctx->aggregate = e ? atoi(e) : 1;
+    e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
+    ctx->span_div = e && atoi(e) > 0 ? atoi(e) : 8;
     return TEC_OK;
 }
 

@@ -77,6 +77,8 @@ struct tec_ctx {
     uint64_t kernel_launches = 0;
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
+    int aggregate = 1;
+    int span_div = 8;
 };
 
 int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
