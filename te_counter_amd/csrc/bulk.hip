@@ -25,7 +25,8 @@ constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
 constexpr uint32_t kCountable = (1u << TEC_CLASS_GENE) | (1u << TEC_CLASS_TE) | (1u << TEC_CLASS_SNRNA);
 constexpr uint32_t kNoName = 0xFFFFFFFFu;
 constexpr int kBlock = 1024;
-constexpr uint32_t kLdsBytes = 79 * 1024;   // per workgroup: two workgroups fit a CU's 160 KiB
+constexpr uint32_t kLdsBytes = 79 * 1024;      // per workgroup: two workgroups fit a CU's 160 KiB
+constexpr uint32_t kLdsMaxBytes = 158 * 1024;  // one workgroup per CU
 
 // floor(x / 10000) for x >= -1 (one 32-bit multiply-high; negative -> -1).
 __device__ __forceinline__ int bucket_of(int x) { return x < 0 ? -1 : (int)((unsigned)x / (unsigned)TEC_BUCKET_SIZE); }
@@ -85,7 +86,10 @@ struct Sink {
             add_n(name, (uint32_t)__builtin_popcountll(active & upto & ~((1ull << lane) - 1ull)));
         }
     }
+    bool mute;  // diagnostic ablation only (TEC_ABLATE): count nothing
+    uint32_t mute_lo, mute_hi;  // diagnostics: skip names in [mute_lo, mute_hi)
     __device__ __forceinline__ void add(uint32_t name) const {
+        if (mute || (name >= mute_lo && name < mute_hi)) return;
         if (aggregate)
             add_runs(name);
         else
@@ -112,7 +116,13 @@ __device__ __forceinline__ uint32_t walk_hits(const tec_entry* __restrict__ ent,
         }
     };
     first_edge(ea);
-    for (uint32_t j = a0 + 1; j < a1; ++j) first_edge(ent[j]);
+    for (uint32_t j = a0 + 1; j < a1; j += 2) {  // two gathers in flight per trip
+        const bool two = j + 1 < a1;
+        const tec_entry e0 = ent[j];
+        const tec_entry e1 = ent[two ? j + 1 : j];
+        first_edge(e0);
+        if (two) first_edge(e1);
+    }
     if (one_bin) return classes;
 
     last = kNoName;
@@ -133,7 +143,13 @@ __device__ __forceinline__ uint32_t walk_hits(const tec_entry* __restrict__ ent,
         }
     };
     second_edge(eb);
-    for (uint32_t j = b0 + 1; j < b1; ++j) second_edge(ent[j]);
+    for (uint32_t j = b0 + 1; j < b1; j += 2) {
+        const bool two = j + 1 < b1;
+        const tec_entry e0 = ent[j];
+        const tec_entry e1 = ent[two ? j + 1 : j];
+        second_edge(e0);
+        if (two) second_edge(e1);
+    }
     return classes;
 }
 
@@ -177,7 +193,9 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     __syncthreads();
-    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0};
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 32u) ? 32u : 0u,
+                    (flags & 16u) ? 32u : ((flags & 32u) ? 0xFFFFFFFFu : 0u)};
+    unsigned sinkhole = 0;  // keeps ablated loads alive
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     uint32_t since_flush = 0;
@@ -208,6 +226,11 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
             ch[k] = __builtin_nontemporal_load(&chrom[ii]);
             un[k].p1 = __builtin_nontemporal_load(&p1[ii]);
             un[k].p2 = __builtin_nontemporal_load(&p2[ii]);
+        }
+        if (flags & 8u) {  // ablation: stream only
+#pragma unroll
+            for (int k = 0; k < U; ++k) sinkhole ^= fl[k] ^ mq[k] ^ (unsigned)ch[k] ^ (unsigned)un[k].p1 ^ (unsigned)un[k].p2;
+            continue;
         }
         // ---- stage 2
         uint32_t a0[U], a1[U], b0[U], b1[U];
@@ -254,12 +277,19 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
                 b1[k] = a1[k];
             }
             ea[k] = ent[a0[k]];
+            eb[k] = ea[k];
             if (b0[k] != a0[k]) eb[k] = ent[b0[k]];
             const unsigned q1 = (unsigned)un[k].p1 / (unsigned)TEC_BUCKET_SIZE;
             const unsigned q2 = ((unsigned)un[k].p2 + 1u) / (unsigned)TEC_BUCKET_SIZE;
             un[k].boundary = un[k].p1 < 0 || un[k].p2 < 0 || un[k].p2 == 0x7FFFFFFF ||
                              (unsigned)un[k].p1 == q1 * TEC_BUCKET_SIZE ||
                              (unsigned)un[k].p2 + 1u == q2 * TEC_BUCKET_SIZE;
+        }
+        if (flags & 4u) {  // ablation: gathers but no walk
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (live[k]) sinkhole ^= (unsigned)ea[k].left ^ (unsigned)eb[k].right ^ a1[k] ^ b1[k];
+            continue;
         }
         // ---- stage 4
 #pragma unroll
@@ -279,6 +309,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
         }
     }
     flush_hist(hist, words, counts);
+    if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     n_assigned = wave_sum(n_assigned);
     n_lowq = wave_sum(n_lowq);
@@ -362,17 +393,22 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const int unroll = ctx->unroll;
     const uint64_t chunk = (uint64_t)unroll * kBlock;
     const uint64_t want = (n + chunk - 1) / chunk;
-    const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * 2);
     const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0;
-    const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, kLdsBytes / 2);
+    // LDS histogram: every name if that fits (two workgroups per CU up to 79 KiB each, else one
+    // workgroup with up to 158 KiB); beyond that the coldest names spill to global atomics.
+    uint32_t budget = ctx->lds_bytes;
+    if (budget == 0) budget = (size_t)ctx->idx.n_names * 2 <= kLdsBytes ? kLdsBytes : kLdsMaxBytes;
+    const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, budget / 2);
     const size_t lds = (size_t)((k_lds + 1) / 2) * 4;
+    const unsigned wg_per_cu = lds <= kLdsBytes ? 2u : 1u;
+    const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * wg_per_cu);
     // spans: ~span_div per workgroup, each a whole number of chunks
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
     hipLaunchKernelGGL(pick_kernel(mixed, unroll), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
                        u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                       (uint32_t)ctx->aggregate);
+                       (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate);
     TEC_HIP(ctx, hipGetLastError());
     TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
     ++ctx->kernel_launches;
@@ -386,12 +422,16 @@ int tec_bulk_init(tec_ctx* ctx) {
     for (int mixed = 0; mixed < 2; ++mixed)
         for (int u : {1, 2, 4, 8})
             TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u)),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4 || u == 8) ? u : 2;
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 1;
+    e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)
+    ctx->ablate = e ? (atoi(e) & 62) : 0;
+    e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup
+    ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 158 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
     e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
     ctx->span_div = e && atoi(e) > 0 ? atoi(e) : 8;
     return TEC_OK;

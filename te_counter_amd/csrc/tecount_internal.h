@@ -78,6 +78,8 @@ struct tec_ctx {
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
     int aggregate = 1;
+    int ablate = 0;  // diagnostics (TEC_ABLATE)
+    uint32_t lds_bytes = 0;  // 0 = automatic
     int span_div = 8;
 };
 
