@@ -325,20 +325,201 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Record kernel: one 64-byte bin record per edge lookup (index.hip), hits collected in registers.
+
+struct BinRec {
+    uint32_t n, off;
+    uint32_t w[12];  // four entries as {left, right, meta}
+    __device__ __forceinline__ tec_entry entry(int k) const {
+        return tec_entry{(int32_t)w[3 * k], (int32_t)w[3 * k + 1], w[3 * k + 2], 0u};
+    }
+};
+
+__device__ __forceinline__ BinRec load_rec(const uint4* __restrict__ recs, uint32_t g) {
+    const uint4* p = recs + 4 * (size_t)g;
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    BinRec r;
+    r.n = q0.x;
+    r.off = q0.y;
+    r.w[0] = q0.z; r.w[1] = q0.w; r.w[2] = q1.x; r.w[3] = q1.y; r.w[4] = q1.z; r.w[5] = q1.w;
+    r.w[6] = q2.x; r.w[7] = q2.y; r.w[8] = q2.z; r.w[9] = q2.w; r.w[10] = q3.x; r.w[11] = q3.y;
+    return r;
+}
+
+// The distinct hit names of one unit in four registers.  Almost every unit hits at most four
+// names; one that overflows is redone by the exact CSR walk (walk_hits).
+struct HitSet {
+    uint32_t h0, h1, h2, h3, n, classes;
+    bool overflow;
+    __device__ __forceinline__ void add(uint32_t meta) {
+        classes |= 1u << ((meta >> TEC_META_CLASS_SHIFT) & 7u);
+        const uint32_t name = meta & kNameMask;
+        if (h0 == name || h1 == name || h2 == name || h3 == name) return;
+        if (n == 0) h0 = name;
+        else if (n == 1) h1 = name;
+        else if (n == 2) h2 = name;
+        else if (n == 3) h3 = name;
+        else overflow = true;
+        if (n < 4) ++n;
+    }
+};
+
+template <class F>
+__device__ __forceinline__ void for_each_entry(const BinRec& r, const tec_entry* __restrict__ ent, F&& f) {
+    if (r.n > 0) f(r.entry(0));
+    if (r.n > 1) f(r.entry(1));
+    if (r.n > 2) f(r.entry(2));
+    if (r.n > 3) f(r.entry(3));
+    for (uint32_t k = 4; k < r.n; ++k) f(ent[r.off + k]);
+}
+
+template <bool MIXED, int U>
+__global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
+                                                               const int32_t* __restrict__ p1,
+                                                               const int32_t* __restrict__ p2,
+                                                               const uint16_t* __restrict__ flag,
+                                                               const uint8_t* __restrict__ mapq, uint64_t n,
+                                                               int mapq_min, unsigned long long* counts,
+                                                               unsigned long long* stats, uint32_t k_lds, uint64_t span,
+                                                               uint32_t flags) {
+    extern __shared__ uint32_t hist[];
+    constexpr uint32_t chunk = U * kBlock;
+    const uint32_t words = (k_lds + 1u) >> 1;
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
+    __syncthreads();
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, false, 0u, 0u};
+    const tec_entry* __restrict__ ent = idx.entries;
+    unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
+    uint32_t since_flush = 0;
+    for (uint64_t s0 = (uint64_t)blockIdx.x * span; s0 < n; s0 += (uint64_t)gridDim.x * span)
+    for (uint64_t base = s0; base < n && base < s0 + span; base += chunk) {
+        if (since_flush + chunk > 65535u) {
+            flush_hist(hist, words, counts);
+            since_flush = 0;
+        }
+        since_flush += chunk;
+        // ---- stage 1: the unit SoA (streamed, non-temporal)
+        unsigned fl[U], mq[U];
+        int ch[U];
+        Unit un[U];
+        bool live[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+            live[k] = i < n;
+            const uint64_t ii = live[k] ? i : 0;
+            fl[k] = __builtin_nontemporal_load(&flag[ii]);
+            mq[k] = __builtin_nontemporal_load(&mapq[ii]);
+            ch[k] = __builtin_nontemporal_load(&chrom[ii]);
+            un[k].p1 = __builtin_nontemporal_load(&p1[ii]);
+            un[k].p2 = __builtin_nontemporal_load(&p2[ii]);
+        }
+        // ---- stage 2: filters, one bin record per edge (a single gather level)
+        BinRec ra[U], rb[U];
+        bool one[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            ra[k].n = rb[k].n = 0;
+            one[k] = true;
+            if (!live[k]) continue;
+            if (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
+                ++n_qc;
+                live[k] = false;
+            } else if ((int)mq[k] < mapq_min) {
+                ++n_lowq;
+                live[k] = false;
+            } else if (ch[k] < 0 || (uint32_t)ch[k] >= idx.n_chrom) {
+                ++n_bad;
+                live[k] = false;
+            } else {
+                const uint32_t nb = idx.chrom_nbins[ch[k]], cb = idx.chrom_base[ch[k]];
+                const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
+                const bool va = un[k].p1 >= 0 && ba < nb, vb = un[k].p2 >= 0 && bb < nb;
+                one[k] = !va || !vb || ba == bb;
+                if (va) ra[k] = load_rec(idx.recs, cb + ba);
+                if (vb && (!va || bb != ba)) rb[k] = load_rec(idx.recs, cb + bb);
+            }
+        }
+        // ---- stage 3: edge tests over the records, distinct names, count
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (!live[k] || (ra[k].n == 0 && rb[k].n == 0)) continue;
+            Unit& u = un[k];
+            const unsigned q1 = (unsigned)u.p1 / (unsigned)TEC_BUCKET_SIZE;
+            const unsigned q2 = ((unsigned)u.p2 + 1u) / (unsigned)TEC_BUCKET_SIZE;
+            u.boundary = u.p1 < 0 || u.p2 < 0 || u.p2 == 0x7FFFFFFF || (unsigned)u.p1 == q1 * TEC_BUCKET_SIZE ||
+                         (unsigned)u.p2 + 1u == q2 * TEC_BUCKET_SIZE;
+            HitSet hs{kNoName, kNoName, kNoName, kNoName, 0u, 0u, false};
+            // With both edges in one bin (or only one edge inside the index) the single list
+            // answers both tests; a feature passing T2 is always filed under p2's bin.
+            const bool both = one[k];
+            for_each_entry(ra[k], ent, [&](const tec_entry e) {
+                if ((test1(e, u) || (both && test2(e, u))) && is_candidate(e, u)) hs.add(e.meta);
+            });
+            for_each_entry(rb[k], ent, [&](const tec_entry e) {
+                if ((test2(e, u) || (both && test1(e, u))) && is_candidate(e, u)) hs.add(e.meta);
+            });
+            if (hs.overflow) {  // more than four distinct names: exact CSR walk (rare)
+                uint32_t a0 = ra[k].off, a1 = ra[k].off + ra[k].n, b0 = rb[k].off, b1 = rb[k].off + rb[k].n;
+                if (ra[k].n == 0) { a0 = b0; a1 = b1; }
+                if (rb[k].n == 0) { b0 = a0; b1 = a1; }
+                const tec_entry ea = ent[a0], eb = ent[b0];
+                if (MIXED) {
+                    const uint32_t classes = walk_hits<false>(ent, u, a0, a1, b0, b1, ea, eb, sink);
+                    ++n_assigned;
+                    if (classes & kCountable)
+                        walk_hits<true>(ent, u, a0, a1, b0, b1, ea, eb, sink);
+                    else if (classes & (1u << TEC_CLASS_ENHANCER))
+                        ++n_enh;
+                } else {
+                    walk_hits<true>(ent, u, a0, a1, b0, b1, ea, eb, sink);
+                    ++n_assigned;
+                }
+                continue;
+            }
+            if (hs.classes == 0) continue;
+            ++n_assigned;
+            if (MIXED && !(hs.classes & kCountable)) {
+                if (hs.classes & (1u << TEC_CLASS_ENHANCER)) ++n_enh;
+                continue;
+            }
+            sink.add(hs.h0);
+            if (hs.n > 1) sink.add(hs.h1);
+            if (hs.n > 2) sink.add(hs.h2);
+            if (hs.n > 3) sink.add(hs.h3);
+        }
+    }
+    flush_hist(hist, words, counts);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+    n_assigned = wave_sum(n_assigned);
+    n_lowq = wave_sum(n_lowq);
+    n_bad = wave_sum(n_bad);
+    n_qc = wave_sum(n_qc);
+    n_enh = wave_sum(n_enh);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_assigned) atomicAdd(&stats[1], (unsigned long long)n_assigned);
+        if (n_lowq) atomicAdd(&stats[2], (unsigned long long)n_lowq);
+        if (n_bad) atomicAdd(&stats[3], (unsigned long long)n_bad);
+        if (n_qc) atomicAdd(&stats[4], (unsigned long long)n_qc);
+        if (n_enh) atomicAdd(&stats[5], (unsigned long long)n_enh);
+    }
+}
+
 typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
                                const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t,
                                uint64_t, uint32_t);
 
 template <int U>
-count_kernel_t pick_mixed(bool mixed) {
+count_kernel_t pick_mixed(bool mixed, bool rec) {
+    if (rec) return mixed ? count_bulk_rec_kernel<true, U> : count_bulk_rec_kernel<false, U>;
     return mixed ? count_bulk_kernel<true, U> : count_bulk_kernel<false, U>;
 }
-count_kernel_t pick_kernel(bool mixed, int unroll) {
+count_kernel_t pick_kernel(bool mixed, int unroll, bool rec) {
     switch (unroll) {
-        case 1: return pick_mixed<1>(mixed);
-        case 8: return pick_mixed<8>(mixed);
-        case 4: return pick_mixed<4>(mixed);
-        default: return pick_mixed<2>(mixed);
+        case 1: return pick_mixed<1>(mixed, rec);
+        case 4: return pick_mixed<4>(mixed, rec);
+        default: return pick_mixed<2>(mixed, rec);
     }
 }
 
@@ -406,7 +587,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
-    hipLaunchKernelGGL(pick_kernel(mixed, unroll), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
+    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
                        u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
                        (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate);
     TEC_HIP(ctx, hipGetLastError());
@@ -420,12 +601,15 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
 int tec_bulk_init(tec_ctx* ctx) {
     // 79 KiB of dynamic LDS per workgroup needs the opt-in above the 64 KiB default
     for (int mixed = 0; mixed < 2; ++mixed)
-        for (int u : {1, 2, 4, 8})
-            TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u)),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int u : {1, 2, 4})
+            for (int rec = 0; rec < 2; ++rec)
+                TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec != 0)),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
-    ctx->unroll = (u == 1 || u == 2 || u == 4 || u == 8) ? u : 2;
+    ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
+    e = getenv("TEC_KERNEL");  // 1: CSR walk kernel, 2: bin-record kernel
+    ctx->kernel_variant = e && atoi(e) == 1 ? 1 : 2;
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 1;
     e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)

@@ -8,6 +8,11 @@
 //   bin_off[n_bins + 1]   u32 CSR offsets; a chromosome's fine bins are contiguous
 //   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by (name id, strand) inside a fine bin
 //   chrom_base[n_chrom], chrom_nbins[n_chrom]
+//   recs[n_bins]          64-byte bin records for the bulk kernel: {n = entries in the bin,
+//                         off = bin_off[bin], the bin's first four entries as {left,right,meta},
+//                         8 B pad}.  One cache line answers an edge lookup for every bin with at
+//                         most four entries (one dependent gather instead of two); longer lists
+//                         continue at entries[off + 4].
 // A feature [left, right] is filed under every fine bin (2^shift bp) that intersects
 // [left-1, right+1]: any read edge that can pass one of the reference's 2-bp edge tests
 // (te_count.py:122,125 / 237,240 / 645,648) then finds the feature in the ONE fine bin of that
@@ -149,7 +154,20 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const size_t o_ent = align_up(o_off + (n_bins + 1) * sizeof(uint32_t), 256);
     const size_t o_cb = align_up(o_ent + std::max<uint64_t>(n_entries, 1) * sizeof(tec_entry), 256);
     const size_t o_cn = align_up(o_cb + n_chrom * sizeof(uint32_t), 256);
-    const size_t total = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
+    const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
+    const size_t total = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * 64, 256);
+    std::vector<uint32_t> recs((size_t)std::max<uint64_t>(n_bins, 1) * 16, 0u);
+    for (uint64_t b = 0; b < n_bins; ++b) {
+        uint32_t* r = &recs[b * 16];
+        const uint32_t a = bin_off[b], cnt = bin_off[b + 1] - a;
+        r[0] = cnt;
+        r[1] = a;
+        for (uint32_t k = 0; k < cnt && k < 4; ++k) {
+            r[2 + 3 * k] = (uint32_t)entries[a + k].left;
+            r[3 + 3 * k] = (uint32_t)entries[a + k].right;
+            r[4 + 3 * k] = entries[a + k].meta;
+        }
+    }
     void* blob = nullptr;
     TEC_HIP(ctx, hipMalloc(&blob, total));
     char* p = static_cast<char*>(blob);
@@ -157,6 +175,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (e == hipSuccess && n_entries) e = hipMemcpy(p + o_ent, entries.data(), n_entries * sizeof(tec_entry), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cb, chrom_base.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cn, chrom_nbins.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p + o_rec, recs.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     unsigned long long* counts = nullptr;
     uint32_t* d_i2e = nullptr;
     if (e == hipSuccess) e = hipMalloc(&d_i2e, (size_t)n_names * sizeof(uint32_t));
@@ -179,6 +198,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     ctx->idx.entries = reinterpret_cast<const tec_entry*>(p + o_ent);
     ctx->idx.chrom_base = reinterpret_cast<const uint32_t*>(p + o_cb);
     ctx->idx.chrom_nbins = reinterpret_cast<const uint32_t*>(p + o_cn);
+    ctx->idx.recs = reinterpret_cast<const uint4*>(p + o_rec);
     ctx->idx.n_chrom = n_chrom;
     ctx->idx.n_names = n_names;
     ctx->idx.shift = shift;

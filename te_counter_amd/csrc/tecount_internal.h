@@ -26,6 +26,7 @@ struct tec_index_dev {
     const tec_entry* entries;     // [n_entries], sorted by name id inside each fine bin
     const uint32_t* chrom_base;   // [n_chrom] first fine bin of each chromosome
     const uint32_t* chrom_nbins;  // [n_chrom] number of fine bins of each chromosome
+    const uint4* recs;            // [n_bins] 64-byte bin records {n, off, 4 x {left,right,meta}, pad}: see index.hip
     uint32_t n_chrom;
     uint32_t n_names;
     int shift;
@@ -78,6 +79,7 @@ struct tec_ctx {
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
     int aggregate = 1;
+    int kernel_variant = 2;
     int ablate = 0;  // diagnostics (TEC_ABLATE)
     uint32_t lds_bytes = 0;  // 0 = automatic
     int span_div = 8;
