@@ -37,7 +37,8 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the annotation (tests)')
     ap.add_argument('--bin-shift', type=int, default=0)
     ap.add_argument('--cpu-sample', type=int, default=8_000_000, help='units timed on the CPU oracle (0 = skip)')
-    ap.add_argument('--traffic', default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass (see profiles/)')
+    ap.add_argument('--traffic', default=None, help='HBM bytes per launch from rocprofv3 --pmc passes; default: profiles/traffic.json entry of this workload')
+    ap.add_argument('--host-stream', action='store_true', help='also time the pinned-host -> HBM -> kernel path (PCIe-inclusive; reported beside, never as value)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -115,7 +116,8 @@ def main():
     if rank == 0:
         total_records = n_units * rec_per_unit * args.steps * world
         value = total_records / elapsed / 1e6
-        alg_bytes = 15.0 * n_units + info['device_bytes'] + 8.0 * eng.n_names
+        # 15 B per unit + index (12 B per entry + 4 B per bin) + 8 B per name
+        alg_bytes = 15.0 * n_units + 12.0 * info['n_entries'] + 4.0 * info['n_bins'] + 8.0 * eng.n_names
         avg_ms = kernel_ms / max(1, launches)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         out = {
@@ -130,17 +132,53 @@ def main():
                        'index': info, 'parallelism': 'dp%d' % world, 'collective': 'rccl all_reduce(sum) of u64 counts' if world > 1 else 'none',
                        'setup_s': round(t_setup, 1)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': float(args.traffic) if args.traffic else None,
-                         'kernel': 'count_bulk_kernel', 'avg_launch_ms': round(avg_ms, 4),
+                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic_for(args, n_units),
+                         'kernel': 'count_bulk_rec_kernel', 'avg_launch_ms': round(avg_ms, 4),
                          'algorithmic_bytes_per_launch': alg_bytes},
             'assigned_frac': round(sstats['assigned'] / max(1, n_units), 4),
         }
+        if args.host_stream and world == 1:
+            out['pcie_inclusive'] = host_stream(eng, units, n_units, rec_per_unit)
         if args.cpu_sample and world == 1:
             out['cpu_baseline'] = cpu_baseline(ann, units, min(args.cpu_sample, n_units), rec_per_unit, eng)
         print(json.dumps(out))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def traffic_for(args, n_units):
+    """HBM bytes per launch of the count kernel from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json, written by tools/traffic.py); null if this workload was not profiled."""
+    if args.traffic:
+        return float(args.traffic)
+    try:
+        table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    except (OSError, ValueError):
+        return None
+    key = '%s/%s/%s/%d' % (args.genome, args.layout, args.order, n_units)
+    e = table.get(key)
+    return float(e['hbm_bytes_per_launch']) if e else None
+
+
+def host_stream(eng, units, n_units, rec_per_unit, batch=1 << 24, reps=3):
+    """Pinned host SoA -> hipMemcpyAsync -> kernel through tec_bulk_submit (double buffered)."""
+    import torch
+    pinned = [torch.from_numpy(u.view(np.int16) if u.dtype == np.uint16 else u).pin_memory() for u in units]
+    views = [p.numpy() for p in pinned]
+    views[3] = views[3].view(np.uint16)
+    best = None
+    for _ in range(reps):
+        eng.bulk_begin(20)
+        t = time.perf_counter()
+        for a in range(0, n_units, batch):
+            eng.bulk_submit(*[v[a:a + batch] for v in views])
+        eng.bulk_finish()
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    return {'value': round(n_units * rec_per_unit / best / 1e6, 1), 'unit': 'Mreads/s',
+            'GB_per_s_over_pcie': round(15.0 * n_units / best / 1e9, 1), 'batch_units': batch,
+            'note': 'pinned host batches streamed with hipMemcpyAsync, copy and compute streams overlapped'}
 
 
 def cpu_baseline(ann, units, n_sample, rec_per_unit, eng):
