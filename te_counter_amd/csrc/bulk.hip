@@ -348,30 +348,44 @@ __device__ __forceinline__ BinRec load_rec(const uint4* __restrict__ recs, uint3
 }
 
 // The distinct hit names of one unit in four registers.  Almost every unit hits at most four
-// names; one that overflows is redone by the exact CSR walk (walk_hits).
+// names; one that overflows is redone by the exact CSR walk (walk_hits).  Written without
+// branches (selects only): on CDNA every divergent `if` costs scalar exec-mask bookkeeping, and
+// the scalar unit is shared by the CU's four SIMDs -- profiles/r01b showed more SALU than VALU
+// instructions in this stage.
 struct HitSet {
     uint32_t h0, h1, h2, h3, n, classes;
     bool overflow;
-    __device__ __forceinline__ void add(uint32_t meta) {
-        classes |= 1u << ((meta >> TEC_META_CLASS_SHIFT) & 7u);
+    __device__ __forceinline__ void add_if(bool hit, uint32_t meta) {
         const uint32_t name = meta & kNameMask;
-        if (h0 == name || h1 == name || h2 == name || h3 == name) return;
-        if (n == 0) h0 = name;
-        else if (n == 1) h1 = name;
-        else if (n == 2) h2 = name;
-        else if (n == 3) h3 = name;
-        else overflow = true;
-        if (n < 4) ++n;
+        classes |= hit ? 1u << ((meta >> TEC_META_CLASS_SHIFT) & 7u) : 0u;
+        const bool fresh = hit & (h0 != name) & (h1 != name) & (h2 != name) & (h3 != name);
+        h0 = (fresh & (n == 0u)) ? name : h0;
+        h1 = (fresh & (n == 1u)) ? name : h1;
+        h2 = (fresh & (n == 2u)) ? name : h2;
+        h3 = (fresh & (n == 3u)) ? name : h3;
+        overflow |= fresh & (n >= 4u);
+        n += (fresh & (n < 4u)) ? 1u : 0u;
     }
 };
 
-template <class F>
-__device__ __forceinline__ void for_each_entry(const BinRec& r, const tec_entry* __restrict__ ent, F&& f) {
-    if (r.n > 0) f(r.entry(0));
-    if (r.n > 1) f(r.entry(1));
-    if (r.n > 2) f(r.entry(2));
-    if (r.n > 3) f(r.entry(3));
-    for (uint32_t k = 4; k < r.n; ++k) f(ent[r.off + k]);
+// Edge tests of one list.  T1_ON / T2_ON say which of the reference's two tests this list can
+// answer (both when the unit's two edges share the bin).  Inline slots beyond the bin's count are
+// zero (left = right = 0) and fail both tests by themselves, so they need no guard.
+__device__ __forceinline__ void scan_record(const BinRec& r, const tec_entry* __restrict__ ent, const Unit& u, bool t1_on,
+                                            bool t2_on, HitSet& hs) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const tec_entry e = r.entry(k);
+        bool hit = ((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0;
+        if (hit && u.boundary) hit = is_candidate_slow(e, u);  // rare: p1 or p2+1 on a 10 kb boundary
+        hs.add_if(hit, e.meta);
+    }
+    for (uint32_t k = 4; k < r.n; ++k) {
+        const tec_entry e = ent[r.off + k];
+        bool hit = ((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0;
+        if (hit && u.boundary) hit = is_candidate_slow(e, u);
+        hs.add_if(hit, e.meta);
+    }
 }
 
 template <bool MIXED, int U>
@@ -388,7 +402,8 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     __syncthreads();
-    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, false, 0u, 0u};
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};
+    unsigned sinkhole = 0;  // keeps ablated loads alive (TEC_ABLATE diagnostics)
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     uint32_t since_flush = 0;
@@ -415,12 +430,18 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
             un[k].p1 = __builtin_nontemporal_load(&p1[ii]);
             un[k].p2 = __builtin_nontemporal_load(&p2[ii]);
         }
+        if (flags & 8u) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) sinkhole ^= fl[k] ^ mq[k] ^ (unsigned)ch[k] ^ (unsigned)un[k].p1 ^ (unsigned)un[k].p2;
+            continue;
+        }
         // ---- stage 2: filters, one bin record per edge (a single gather level)
         BinRec ra[U], rb[U];
         bool one[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            ra[k].n = rb[k].n = 0;
+            ra[k] = BinRec{};  // zero entries fail both edge tests
+            rb[k] = BinRec{};
             one[k] = true;
             if (!live[k]) continue;
             if (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
@@ -441,6 +462,12 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
                 if (vb && (!va || bb != ba)) rb[k] = load_rec(idx.recs, cb + bb);
             }
         }
+        if (flags & 4u) {
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (live[k]) sinkhole ^= ra[k].n ^ rb[k].n ^ ra[k].w[11] ^ rb[k].w[5];
+            continue;
+        }
         // ---- stage 3: edge tests over the records, distinct names, count
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -454,12 +481,8 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
             // With both edges in one bin (or only one edge inside the index) the single list
             // answers both tests; a feature passing T2 is always filed under p2's bin.
             const bool both = one[k];
-            for_each_entry(ra[k], ent, [&](const tec_entry e) {
-                if ((test1(e, u) || (both && test2(e, u))) && is_candidate(e, u)) hs.add(e.meta);
-            });
-            for_each_entry(rb[k], ent, [&](const tec_entry e) {
-                if ((test2(e, u) || (both && test1(e, u))) && is_candidate(e, u)) hs.add(e.meta);
-            });
+            scan_record(ra[k], ent, u, true, both, hs);
+            scan_record(rb[k], ent, u, both, true, hs);
             if (hs.overflow) {  // more than four distinct names: exact CSR walk (rare)
                 uint32_t a0 = ra[k].off, a1 = ra[k].off + ra[k].n, b0 = rb[k].off, b1 = rb[k].off + rb[k].n;
                 if (ra[k].n == 0) { a0 = b0; a1 = b1; }
@@ -491,6 +514,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
         }
     }
     flush_hist(hist, words, counts);
+    if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     n_assigned = wave_sum(n_assigned);
     n_lowq = wave_sum(n_lowq);

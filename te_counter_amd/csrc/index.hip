@@ -147,12 +147,33 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
             });
     }
 
+    // Exact duplicates inside a bin (the same exon listed once per transcript) change no hit
+    // set -- hits are sets of names / (name, strand) pairs and class bits are OR-ed -- drop them.
+    {
+        std::vector<uint32_t> new_off(n_bins + 1, 0);
+        uint64_t w = 0;
+        for (uint64_t b = 0; b < n_bins; ++b) {
+            new_off[b] = (uint32_t)w;
+            for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) {
+                if (i > bin_off[b] && w > new_off[b]) {
+                    const tec_entry& q = entries[w - 1];
+                    if (q.left == entries[i].left && q.right == entries[i].right && q.meta == entries[i].meta) continue;
+                }
+                entries[w++] = entries[i];
+            }
+        }
+        new_off[n_bins] = (uint32_t)w;
+        bin_off.swap(new_off);
+        entries.resize(w);
+    }
+    const uint64_t n_entries_kept = entries.size();
+
     // upload as one blob
     TEC_HIP(ctx, hipSetDevice(ctx->device));
     TEC_HIP(ctx, hipDeviceSynchronize());
     const size_t o_off = 0;
     const size_t o_ent = align_up(o_off + (n_bins + 1) * sizeof(uint32_t), 256);
-    const size_t o_cb = align_up(o_ent + std::max<uint64_t>(n_entries, 1) * sizeof(tec_entry), 256);
+    const size_t o_cb = align_up(o_ent + std::max<uint64_t>(n_entries_kept, 1) * sizeof(tec_entry), 256);
     const size_t o_cn = align_up(o_cb + n_chrom * sizeof(uint32_t), 256);
     const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
     const size_t total = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * 64, 256);
@@ -172,7 +193,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     TEC_HIP(ctx, hipMalloc(&blob, total));
     char* p = static_cast<char*>(blob);
     hipError_t e = hipMemcpy(p + o_off, bin_off.data(), (n_bins + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_entries) e = hipMemcpy(p + o_ent, entries.data(), n_entries * sizeof(tec_entry), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_entries_kept) e = hipMemcpy(p + o_ent, entries.data(), n_entries_kept * sizeof(tec_entry), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cb, chrom_base.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cn, chrom_nbins.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_rec, recs.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -204,7 +225,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     ctx->idx.shift = shift;
     ctx->idx.class_mask = class_mask;
     ctx->int2ext.swap(int2ext);
-    ctx->n_entries = n_entries;
+    ctx->n_entries = n_entries_kept;
     ctx->n_bins = n_bins;
     ctx->index_bytes = total;
     ctx->have_index = true;
