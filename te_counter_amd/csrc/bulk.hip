@@ -368,23 +368,20 @@ struct HitSet {
     }
 };
 
-// Edge tests of one list.  T1_ON / T2_ON say which of the reference's two tests this list can
-// answer (both when the unit's two edges share the bin).  Inline slots beyond the bin's count are
+// Edge tests of one list for a unit that is NOT on a 10 kb boundary (every hit is then a bucket
+// candidate, see is_candidate).  t1_on / t2_on say which of the reference's two tests this list
+// can answer (both when the unit's two edges share the bin).  Inline slots beyond the bin's count are
 // zero (left = right = 0) and fail both tests by themselves, so they need no guard.
 __device__ __forceinline__ void scan_record(const BinRec& r, const tec_entry* __restrict__ ent, const Unit& u, bool t1_on,
                                             bool t2_on, HitSet& hs) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const tec_entry e = r.entry(k);
-        bool hit = ((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0;
-        if (hit && u.boundary) hit = is_candidate_slow(e, u);  // rare: p1 or p2+1 on a 10 kb boundary
-        hs.add_if(hit, e.meta);
+        hs.add_if(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
     }
     for (uint32_t k = 4; k < r.n; ++k) {
         const tec_entry e = ent[r.off + k];
-        bool hit = ((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0;
-        if (hit && u.boundary) hit = is_candidate_slow(e, u);
-        hs.add_if(hit, e.meta);
+        hs.add_if(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
     }
 }
 
@@ -481,23 +478,26 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
             // With both edges in one bin (or only one edge inside the index) the single list
             // answers both tests; a feature passing T2 is always filed under p2's bin.
             const bool both = one[k];
-            scan_record(ra[k], ent, u, true, both, hs);
-            scan_record(rb[k], ent, u, both, true, hs);
-            if (hs.overflow) {  // more than four distinct names: exact CSR walk (rare)
+            if (!u.boundary) {
+                scan_record(ra[k], ent, u, true, both, hs);
+                scan_record(rb[k], ent, u, both, true, hs);
+            }
+            // exact CSR walk for the rare rest: p1 or p2+1 on a 10 kb boundary (the reference's
+            // bucket-candidate rule can bite there), or more than four distinct names
+            if (u.boundary || hs.overflow) {
                 uint32_t a0 = ra[k].off, a1 = ra[k].off + ra[k].n, b0 = rb[k].off, b1 = rb[k].off + rb[k].n;
                 if (ra[k].n == 0) { a0 = b0; a1 = b1; }
                 if (rb[k].n == 0) { b0 = a0; b1 = a1; }
                 const tec_entry ea = ent[a0], eb = ent[b0];
                 if (MIXED) {
                     const uint32_t classes = walk_hits<false>(ent, u, a0, a1, b0, b1, ea, eb, sink);
-                    ++n_assigned;
+                    if (classes) ++n_assigned;
                     if (classes & kCountable)
                         walk_hits<true>(ent, u, a0, a1, b0, b1, ea, eb, sink);
                     else if (classes & (1u << TEC_CLASS_ENHANCER))
                         ++n_enh;
                 } else {
-                    walk_hits<true>(ent, u, a0, a1, b0, b1, ea, eb, sink);
-                    ++n_assigned;
+                    if (walk_hits<true>(ent, u, a0, a1, b0, b1, ea, eb, sink)) ++n_assigned;
                 }
                 continue;
             }
@@ -635,7 +635,7 @@ int tec_bulk_init(tec_ctx* ctx) {
     e = getenv("TEC_KERNEL");  // 1: CSR walk kernel, 2: bin-record kernel
     ctx->kernel_variant = e && atoi(e) == 1 ? 1 : 2;
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
-    ctx->aggregate = e ? atoi(e) : 1;
+    ctx->aggregate = e ? atoi(e) : 0;
     e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)
     ctx->ablate = e ? (atoi(e) & 62) : 0;
     e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup

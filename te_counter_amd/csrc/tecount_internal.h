@@ -78,7 +78,7 @@ struct tec_ctx {
     uint64_t kernel_launches = 0;
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
-    int aggregate = 1;
+    int aggregate = 0;
     int kernel_variant = 2;
     int ablate = 0;  // diagnostics (TEC_ABLATE)
     uint32_t lds_bytes = 0;  // 0 = automatic
