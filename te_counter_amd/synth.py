@@ -197,3 +197,77 @@ def make_units(ann, n_units, seed, paired, order='shuffled', chunk=1 << 22):
     elif order != 'shuffled':
         raise ValueError(order)
     return tuple(units)
+
+
+# --------------------------------------------------------------------------- single cell (config 4)
+
+_BASES = np.frombuffer(b'ACGT', np.uint8)
+
+
+def make_whitelist_bytes(n, length=16, seed=7):
+    """n distinct random `length`-mers, sorted bytewise; uint8[n, 24] zero padded (te_count.py:338
+    gives a barcode the id of its row in this order)."""
+    rng = np.random.default_rng(seed)
+    codes = np.unique(rng.integers(0, 4 ** length, int(n * 1.05), dtype=np.int64))[:n]
+    while len(codes) < n:
+        codes = np.unique(np.concatenate([codes, rng.integers(0, 4 ** length, n, dtype=np.int64)]))[:n]
+    out = np.zeros((n, 24), np.uint8)
+    for j in range(length):  # most significant base first: numeric order == bytewise order (A<C<G<T)
+        out[:, j] = _BASES[(codes >> (2 * (length - 1 - j))) & 3]
+    return out
+
+
+def make_sc_arrays(ann, n_records, n_cells=10000, n_whitelist=737280, seed=2004, reads_per_umi=3.0, umi_len=12,
+                   off_whitelist=0.02, order='shuffled'):
+    """10x-style SE records as the arrays tec_sc_submit takes (BASELINE config 4: 10 k cells x 5 k
+    reads, whitelist of 737 280 16-mers, 12-mer UMIs, ~3 reads per (CB,UB)).  Every (CB,UB) key stays
+    on one (chromosome, strand) class, i.e. inside the reference's determinism envelope
+    (SURVEY.md 3.4).  Returns (arrays dict, whitelist uint8[n,24], class tables)."""
+    rng = np.random.default_rng(seed)
+    wl = make_whitelist_bytes(n_whitelist)
+    cell_rows = rng.choice(n_whitelist, n_cells, replace=False)
+    n_keys = max(1, int(n_records / reads_per_umi))
+    reps = rng.geometric(1.0 / reads_per_umi, n_keys)
+    reps = reps[np.cumsum(reps) <= n_records]
+    n_keys = len(reps)
+    n = int(reps.sum())
+    key_cell = cell_rows[rng.integers(0, n_cells, n_keys)]
+    key_umi = rng.integers(0, 4, (n_keys, umi_len), dtype=np.int64)
+    # positions per key, with the bulk generator's placement
+    chrom, p1, _, _, _ = make_units(ann, n_keys, seed=seed + 1, paired=False)
+    key_rev = rng.integers(0, 2, n_keys)
+    rec_key = np.repeat(np.arange(n_keys), reps)
+    if order == 'shuffled':
+        rec_key = rec_key[rng.permutation(n)]
+    pos = np.maximum(0, p1[rec_key] + rng.integers(-3, 4, n)).astype(np.int32)
+    cb = wl[key_cell[rec_key]].copy()
+    bad = rng.random(n) < off_whitelist
+    cb[bad, 15] = np.where(cb[bad, 15] == ord('A'), ord('C'), ord('A'))  # mostly off the whitelist
+    ub = np.zeros((n, 24), np.uint8)
+    ub[:, :umi_len] = _BASES[key_umi[rec_key]]
+    flag = np.where(key_rev[rec_key] == 1, 0x10, 0).astype(np.uint16)
+    x = rng.random(n)
+    flag |= np.where(x < 0.01, 0x4, np.where(x < 0.03, 0x400, np.where(x < 0.035, 0x200, 0))).astype(np.uint16)
+    mapq = _MAPQ_VALUES[rng.choice(len(_MAPQ_VALUES), n, p=_MAPQ_P)]
+    # read-side chromosome classes: one per header name; a few records on contigs that part 1 skips
+    names = list(ann.chrom_names) + ['chrUn_KI270742v1', 'chr1_KI270706v1_random']
+    cls = chrom[rec_key].astype(np.int32)
+    stray = rng.random(n) < 0.02
+    cls[stray] = len(ann.chrom_names) + rng.integers(0, 2, int(stray.sum()))
+    cls[chrom[rec_key] < 0] = len(ann.chrom_names)
+    arrays = {'cls': cls, 'pos': pos, 'end': (pos + 98).astype(np.int32), 'flag': flag, 'mapq': mapq, 'cb24': cb,
+              'ub24': ub, 'tagflags': np.full(n, 3, np.uint8)}
+    class_chrom = np.array([ann.flat._chrom_lookup.get(nm.replace('chr', ''), -1) for nm in names], np.int32)
+    class_skip = np.array([('_' in nm.replace('chr', '')) or ('alt' in nm.replace('chr', '')) for nm in names], np.uint8)
+    return arrays, wl, (names, class_chrom, class_skip)
+
+
+def sc_arrays_to_records(arrays, names):
+    """The same records as dicts (oracle / reference schema) -- small inputs only."""
+    recs = []
+    for i in range(len(arrays['pos'])):
+        recs.append({'flag': int(arrays['flag'][i]), 'mapq': int(arrays['mapq'][i]), 'rname': names[arrays['cls'][i]],
+                     'pos': int(arrays['pos'][i]), 'end': int(arrays['end'][i]),
+                     'tags': {'CB': bytes(arrays['cb24'][i]).rstrip(b'\0').decode(),
+                              'UB': bytes(arrays['ub24'][i]).rstrip(b'\0').decode()}})
+    return recs

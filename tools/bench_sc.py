@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Single-cell path benchmark (BASELINE config 4: 10 k cells x 5 k reads = 5e7 SE records,
+737 280-barcode whitelist, 12-mer UMIs, ~3 reads per (CB,UB), bundle threshold 1e7 -> >= 2 spill
+epochs).  Times tec_sc_* end to end from host SoA batches (H2D copies included) and checks a
+reduced-size run of the same generator against the Python oracle.
+
+    python tools/bench_sc.py [--records N] [--check 150000]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(eng, arrays, wl, tables, maxcells, stranded, bundle_keys, batch=1 << 22):
+    names, class_chrom, class_skip = tables
+    t = {}
+    t0 = time.perf_counter()
+    eng.sc_begin(stranded, 20, wl, bundle_keys, class_chrom, class_skip)
+    n = len(arrays['pos'])
+    for a in range(0, n, batch):
+        eng.sc_submit(*[arrays[k][a:a + batch] for k in ('cls', 'pos', 'end', 'flag', 'mapq', 'cb24', 'ub24', 'tagflags')])
+    t['submit'] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    ids, counts, first = eng.sc_part1()
+    t['part1'] = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    order = np.lexsort((first, -counts.astype(np.int64)))
+    selected = np.sort(ids[order[0:maxcells + 1000]])
+    out = eng.sc_part23(selected)
+    t['part23'] = time.perf_counter() - t2
+    st = eng.sc_stats()
+    eng.sc_end()
+    t['total'] = time.perf_counter() - t0
+    return out, st, t, (ids, counts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--records', type=int, default=50_000_000)
+    ap.add_argument('--cells', type=int, default=10000)
+    ap.add_argument('--check', type=int, default=150000, help='records of the reduced-size oracle check (0 = skip)')
+    ap.add_argument('--strand', action='store_true')
+    args = ap.parse_args()
+    from te_counter_amd import Engine, synth
+    ann = synth.make_annotation('hg38')
+    eng = Engine(0)
+    eng.upload_index(ann.flat)
+    res = {}
+    if args.check:
+        from oracle import te_oracle as orc
+        small = synth.make_annotation('hg38', scale=0.01)
+        eng.upload_index(small.flat)
+        arrays, wl, tables = synth.make_sc_arrays(small, args.check, n_cells=40, n_whitelist=5000, seed=11)
+        thr = max(1000, args.check // 8)
+        out, st, _, _ = run(eng, arrays, wl, tables, 25, args.strand, thr)
+        wl_str = [bytes(r).rstrip(b'\0').decode() for r in wl]
+        feats = [{'chr': small.flat.chrom_keys[c], 'left': int(l), 'right': int(r), 'strand': '+-'[(m >> 29) & 1],
+                  'name': 'x', 'type': 'TE' if ((m >> 26) & 7) == 2 else 'protein_coding', 'ensg': small.flat.names[m & ((1 << 26) - 1)]}
+                 for c, l, r, m in zip(small.flat.chrom_id.tolist(), small.flat.left.tolist(), small.flat.right.tolist(), small.flat.meta.tolist())]
+        recs = synth.sc_arrays_to_records(arrays, tables[0])
+        want, wbc, _ = orc.sc_count(feats, recs, wl_str, 25, strand=args.strand, bundle_threshold=thr)
+        got = {}
+        for c, nm, v in zip(out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()):
+            got.setdefault(small.flat.names[nm], {})[wl_str[c]] = v
+        want_nz = {k: v for k, v in want.items() if v}
+        ok = got == want_nz and [(wl_str[c], h) for c, h in zip(out['cells'].tolist(), out['cell_hits'].tolist())] == list(wbc.items())
+        res['oracle_check'] = {'records': args.check, 'bundles': st['bundles'], 'identical': bool(ok)}
+        if not ok:
+            print(json.dumps(res))
+            sys.exit('PARITY FAILURE in the reduced-size single-cell check')
+        eng.upload_index(ann.flat)
+    t0 = time.time()
+    arrays, wl, tables = synth.make_sc_arrays(ann, args.records, n_cells=args.cells)
+    res['gen_s'] = round(time.time() - t0, 1)
+    n = len(arrays['pos'])
+    run(eng, {k: v[:1 << 20] for k, v in arrays.items()}, wl, tables, args.cells, args.strand, 10_000_000)  # warm-up
+    out, st, t, _ = run(eng, arrays, wl, tables, args.cells, args.strand, 10_000_000)
+    res.update({'metric': 'Mreads/s single-cell (--sc --se) end to end from host SoA batches', 'records': n,
+                'value': round(n / t['total'] / 1e6, 2), 'unit': 'Mreads/s', 'seconds': {k: round(v, 3) for k, v in t.items()},
+                'stats': st, 'cells_with_hits': int(len(out['cells'])), 'coo_nnz': int(len(out['coo_cell']))})
+    print(json.dumps(res))
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()
