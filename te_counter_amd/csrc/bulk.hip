@@ -326,24 +326,36 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Record kernel: one 64-byte bin record per edge lookup (index.hip), hits collected in registers.
+// Record kernel: one compact bin record per edge lookup (index.hip), hits collected in registers.
 
+// Compact bin record (index.hip): {n, off, NE x {left16 | right16 << 16, meta}}; coordinates are
+// relative to (bin start - 1) and clamped to the bin, which is all the two edge tests need for a
+// position inside the bin.  NE = 3 -> 32 bytes (two 16-byte gathers), NE = 7 -> 64 bytes.
+template <int NE>
 struct BinRec {
     uint32_t n, off;
-    uint32_t w[12];  // four entries as {left, right, meta}
-    __device__ __forceinline__ tec_entry entry(int k) const {
-        return tec_entry{(int32_t)w[3 * k], (int32_t)w[3 * k + 1], w[3 * k + 2], 0u};
-    }
+    uint32_t lr[NE], meta[NE];
 };
 
-__device__ __forceinline__ BinRec load_rec(const uint4* __restrict__ recs, uint32_t g) {
-    const uint4* p = recs + 4 * (size_t)g;
-    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    BinRec r;
-    r.n = q0.x;
-    r.off = q0.y;
-    r.w[0] = q0.z; r.w[1] = q0.w; r.w[2] = q1.x; r.w[3] = q1.y; r.w[4] = q1.z; r.w[5] = q1.w;
-    r.w[6] = q2.x; r.w[7] = q2.y; r.w[8] = q2.z; r.w[9] = q2.w; r.w[10] = q3.x; r.w[11] = q3.y;
+template <int NE>
+__device__ __forceinline__ BinRec<NE> load_rec(const uint4* __restrict__ recs, uint32_t g) {
+    constexpr int Q = (NE + 1) / 2;  // 16-byte pieces per record
+    const uint4* p = recs + (size_t)Q * g;
+    uint4 q[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) q[i] = p[i];
+    BinRec<NE> r;
+    r.n = q[0].x;
+    r.off = q[0].y;
+    r.lr[0] = q[0].z;
+    r.meta[0] = q[0].w;
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+        r.lr[2 * i - 1] = q[i].x;
+        r.meta[2 * i - 1] = q[i].y;
+        r.lr[2 * i] = q[i].z;
+        r.meta[2 * i] = q[i].w;
+    }
     return r;
 }
 
@@ -369,23 +381,26 @@ struct HitSet {
 };
 
 // Edge tests of one list for a unit that is NOT on a 10 kb boundary (every hit is then a bucket
-// candidate, see is_candidate).  t1_on / t2_on say which of the reference's two tests this list
-// can answer (both when the unit's two edges share the bin).  Inline slots beyond the bin's count are
-// zero (left = right = 0) and fail both tests by themselves, so they need no guard.
-__device__ __forceinline__ void scan_record(const BinRec& r, const tec_entry* __restrict__ ent, const Unit& u, bool t1_on,
-                                            bool t2_on, HitSet& hs) {
+// candidate, see is_candidate).  t1_on / t2_on: is p1 / p2 inside this record's bin?  x1 / x2 are
+// the positions relative to (bin start - 1).  Inline slots beyond the bin's count are zero and
+// fail both tests by themselves; entries beyond NE continue in the CSR list (absolute tests).
+template <int NE>
+__device__ __forceinline__ void scan_record(const BinRec<NE>& r, const tec_entry* __restrict__ ent, const Unit& u, int x1,
+                                            int x2, bool t1_on, bool t2_on, HitSet& hs) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const tec_entry e = r.entry(k);
-        hs.add_if(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
+    for (int k = 0; k < NE; ++k) {
+        const int l = (int)(r.lr[k] & 0xFFFFu), g = (int)(r.lr[k] >> 16);
+        const bool t1 = t1_on & (x1 >= l) & (x1 < g);
+        const bool t2 = t2_on & (x2 > l) & (x2 <= g);
+        hs.add_if(t1 | t2, r.meta[k]);
     }
-    for (uint32_t k = 4; k < r.n; ++k) {
+    for (uint32_t k = NE; k < r.n; ++k) {
         const tec_entry e = ent[r.off + k];
         hs.add_if(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
     }
 }
 
-template <bool MIXED, int U>
+template <bool MIXED, int U, int NE>
 __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
                                                                const int32_t* __restrict__ p1,
                                                                const int32_t* __restrict__ p2,
@@ -433,13 +448,15 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
             continue;
         }
         // ---- stage 2: filters, one bin record per edge (a single gather level)
-        BinRec ra[U], rb[U];
+        BinRec<NE> ra[U], rb[U];
         bool one[U];
+        int xa1[U], xa2[U], xb2[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            ra[k] = BinRec{};  // zero entries fail both edge tests
-            rb[k] = BinRec{};
-            one[k] = true;
+            ra[k] = BinRec<NE>{};  // zero entries fail both edge tests
+            rb[k] = BinRec<NE>{};
+            one[k] = false;
+            xa1[k] = xa2[k] = xb2[k] = 0;
             if (!live[k]) continue;
             if (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
                 ++n_qc;
@@ -454,15 +471,18 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
                 const uint32_t nb = idx.chrom_nbins[ch[k]], cb = idx.chrom_base[ch[k]];
                 const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
                 const bool va = un[k].p1 >= 0 && ba < nb, vb = un[k].p2 >= 0 && bb < nb;
-                one[k] = !va || !vb || ba == bb;
-                if (va) ra[k] = load_rec(idx.recs, cb + ba);
-                if (vb && (!va || bb != ba)) rb[k] = load_rec(idx.recs, cb + bb);
+                one[k] = va && vb && ba == bb;  // both edges in one bin: its record answers both tests
+                if (va) ra[k] = load_rec<NE>(idx.recs, cb + ba);
+                if (vb && !one[k]) rb[k] = load_rec<NE>(idx.recs, cb + bb);
+                xa1[k] = un[k].p1 - (int)(ba << idx.shift) + 1;
+                xa2[k] = un[k].p2 - (int)(ba << idx.shift) + 1;
+                xb2[k] = un[k].p2 - (int)(bb << idx.shift) + 1;
             }
         }
         if (flags & 4u) {
 #pragma unroll
             for (int k = 0; k < U; ++k)
-                if (live[k]) sinkhole ^= ra[k].n ^ rb[k].n ^ ra[k].w[11] ^ rb[k].w[5];
+                if (live[k]) sinkhole ^= ra[k].n ^ rb[k].n ^ ra[k].meta[NE - 1] ^ rb[k].lr[NE - 1];
             continue;
         }
         // ---- stage 3: edge tests over the records, distinct names, count
@@ -475,12 +495,9 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
             u.boundary = u.p1 < 0 || u.p2 < 0 || u.p2 == 0x7FFFFFFF || (unsigned)u.p1 == q1 * TEC_BUCKET_SIZE ||
                          (unsigned)u.p2 + 1u == q2 * TEC_BUCKET_SIZE;
             HitSet hs{kNoName, kNoName, kNoName, kNoName, 0u, 0u, false};
-            // With both edges in one bin (or only one edge inside the index) the single list
-            // answers both tests; a feature passing T2 is always filed under p2's bin.
-            const bool both = one[k];
             if (!u.boundary) {
-                scan_record(ra[k], ent, u, true, both, hs);
-                scan_record(rb[k], ent, u, both, true, hs);
+                scan_record<NE>(ra[k], ent, u, xa1[k], xa2[k], true, one[k], hs);
+                scan_record<NE>(rb[k], ent, u, 0, xb2[k], false, true, hs);
             }
             // exact CSR walk for the rare rest: p1 or p2+1 on a 10 kb boundary (the reference's
             // bucket-candidate rule can bite there), or more than four distinct names
@@ -535,15 +552,17 @@ typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, co
                                uint64_t, uint32_t);
 
 template <int U>
-count_kernel_t pick_mixed(bool mixed, bool rec) {
-    if (rec) return mixed ? count_bulk_rec_kernel<true, U> : count_bulk_rec_kernel<false, U>;
+count_kernel_t pick_mixed(bool mixed, int rec_ne) {
+    if (rec_ne == 3) return mixed ? count_bulk_rec_kernel<true, U, 3> : count_bulk_rec_kernel<false, U, 3>;
+    if (rec_ne == 7) return mixed ? count_bulk_rec_kernel<true, U, 7> : count_bulk_rec_kernel<false, U, 7>;
     return mixed ? count_bulk_kernel<true, U> : count_bulk_kernel<false, U>;
 }
-count_kernel_t pick_kernel(bool mixed, int unroll, bool rec) {
+// rec_ne: inline entries per bin record (3 or 7), 0 = the CSR walk kernel
+count_kernel_t pick_kernel(bool mixed, int unroll, int rec_ne) {
     switch (unroll) {
-        case 1: return pick_mixed<1>(mixed, rec);
-        case 4: return pick_mixed<4>(mixed, rec);
-        default: return pick_mixed<2>(mixed, rec);
+        case 1: return pick_mixed<1>(mixed, rec_ne);
+        case 4: return pick_mixed<4>(mixed, rec_ne);
+        default: return pick_mixed<2>(mixed, rec_ne);
     }
 }
 
@@ -611,7 +630,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
-    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
+    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 ? ctx->rec_ne : 0), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
                        u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
                        (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate);
     TEC_HIP(ctx, hipGetLastError());
@@ -626,14 +645,16 @@ int tec_bulk_init(tec_ctx* ctx) {
     // 79 KiB of dynamic LDS per workgroup needs the opt-in above the 64 KiB default
     for (int mixed = 0; mixed < 2; ++mixed)
         for (int u : {1, 2, 4})
-            for (int rec = 0; rec < 2; ++rec)
-                TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec != 0)),
+            for (int rec : {0, 3, 7})
+                TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec)),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
     e = getenv("TEC_KERNEL");  // 1: CSR walk kernel, 2: bin-record kernel
     ctx->kernel_variant = e && atoi(e) == 1 ? 1 : 2;
+    e = getenv("TEC_REC_NE");  // inline entries per bin record: 3 (32-byte records) or 7 (64-byte)
+    ctx->rec_ne_wanted = e && atoi(e) == 7 ? 7 : 3;
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 0;
     e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)

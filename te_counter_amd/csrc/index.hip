@@ -8,11 +8,12 @@
 //   bin_off[n_bins + 1]   u32 CSR offsets; a chromosome's fine bins are contiguous
 //   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by (name id, strand) inside a fine bin
 //   chrom_base[n_chrom], chrom_nbins[n_chrom]
-//   recs[n_bins]          64-byte bin records for the bulk kernel: {n = entries in the bin,
-//                         off = bin_off[bin], the bin's first four entries as {left,right,meta},
-//                         8 B pad}.  One cache line answers an edge lookup for every bin with at
-//                         most four entries (one dependent gather instead of two); longer lists
-//                         continue at entries[off + 4].
+//   recs[n_bins]          compact bin records for the bulk kernel: {n = entries in the bin,
+//                         off = bin_off[bin], the bin's first NE entries as {left16 | right16<<16,
+//                         meta}} with coordinates relative to (bin start - 1) and clamped to the
+//                         bin -- 32 bytes for NE = 3.  One record answers an edge lookup for every
+//                         bin with at most NE entries (one dependent gather level instead of two);
+//                         longer lists continue at entries[off + NE].
 // A feature [left, right] is filed under every fine bin (2^shift bp) that intersects
 // [left-1, right+1]: any read edge that can pass one of the reference's 2-bp edge tests
 // (te_count.py:122,125 / 237,240 / 645,648) then finds the feature in the ONE fine bin of that
@@ -175,19 +176,29 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const size_t o_ent = align_up(o_off + (n_bins + 1) * sizeof(uint32_t), 256);
     const size_t o_cb = align_up(o_ent + std::max<uint64_t>(n_entries_kept, 1) * sizeof(tec_entry), 256);
     const size_t o_cn = align_up(o_cb + n_chrom * sizeof(uint32_t), 256);
+    // compact bin records for the bulk kernel (coordinates relative to bin start - 1, 16 bits)
+    const int rec_ne = shift <= 15 ? ctx->rec_ne_wanted : 0;
+    const size_t rec_words = rec_ne ? 2 + 2 * (size_t)rec_ne : 0;
     const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
-    const size_t total = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * 64, 256);
-    std::vector<uint32_t> recs((size_t)std::max<uint64_t>(n_bins, 1) * 16, 0u);
-    for (uint64_t b = 0; b < n_bins; ++b) {
-        uint32_t* r = &recs[b * 16];
-        const uint32_t a = bin_off[b], cnt = bin_off[b + 1] - a;
-        r[0] = cnt;
-        r[1] = a;
-        for (uint32_t k = 0; k < cnt && k < 4; ++k) {
-            r[2 + 3 * k] = (uint32_t)entries[a + k].left;
-            r[3 + 3 * k] = (uint32_t)entries[a + k].right;
-            r[4 + 3 * k] = entries[a + k].meta;
-        }
+    const size_t total = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * rec_words * 4 + 16, 256);
+    std::vector<uint32_t> recs((size_t)std::max<uint64_t>(n_bins, 1) * rec_words + 4, 0u);
+    if (rec_ne) {
+        const int64_t width = (int64_t)1 << shift;
+        uint64_t b = 0;
+        for (uint32_t c = 0; c < n_chrom; ++c)
+            for (uint32_t lb = 0; lb < chrom_nbins[c]; ++lb, ++b) {
+                uint32_t* r = &recs[b * rec_words];
+                const uint32_t a = bin_off[b], cnt = bin_off[b + 1] - a;
+                const int64_t start = (int64_t)lb << shift;
+                r[0] = cnt;
+                r[1] = a;
+                for (uint32_t k = 0; k < cnt && k < (uint32_t)rec_ne; ++k) {
+                    const int64_t l = std::min<int64_t>(std::max<int64_t>((int64_t)entries[a + k].left - start + 1, 0), width + 2);
+                    const int64_t g = std::min<int64_t>(std::max<int64_t>((int64_t)entries[a + k].right - start + 1, 0), width + 2);
+                    r[2 + 2 * k] = (uint32_t)l | ((uint32_t)g << 16);
+                    r[3 + 2 * k] = entries[a + k].meta;
+                }
+            }
     }
     void* blob = nullptr;
     TEC_HIP(ctx, hipMalloc(&blob, total));
@@ -220,6 +231,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     ctx->idx.chrom_base = reinterpret_cast<const uint32_t*>(p + o_cb);
     ctx->idx.chrom_nbins = reinterpret_cast<const uint32_t*>(p + o_cn);
     ctx->idx.recs = reinterpret_cast<const uint4*>(p + o_rec);
+    ctx->rec_ne = rec_ne;
     ctx->idx.n_chrom = n_chrom;
     ctx->idx.n_names = n_names;
     ctx->idx.shift = shift;

@@ -26,7 +26,7 @@ struct tec_index_dev {
     const tec_entry* entries;     // [n_entries], sorted by name id inside each fine bin
     const uint32_t* chrom_base;   // [n_chrom] first fine bin of each chromosome
     const uint32_t* chrom_nbins;  // [n_chrom] number of fine bins of each chromosome
-    const uint4* recs;            // [n_bins] 64-byte bin records {n, off, 4 x {left,right,meta}, pad}: see index.hip
+    const uint4* recs;            // [n_bins] compact bin records {n, off, NE x {left16|right16<<16, meta}}: see index.hip
     uint32_t n_chrom;
     uint32_t n_names;
     int shift;
@@ -80,6 +80,8 @@ struct tec_ctx {
     int unroll = 2;  // units carried per lane by the count kernel
     int aggregate = 0;
     int kernel_variant = 2;
+    int rec_ne_wanted = 3;  // inline entries per bin record asked for (TEC_REC_NE)
+    int rec_ne = 0;         // ... of the resident index (0: no records, bin shift too wide)
     int ablate = 0;  // diagnostics (TEC_ABLATE)
     uint32_t lds_bytes = 0;  // 0 = automatic
     int span_div = 8;
