@@ -20,6 +20,7 @@
 // edge position.  Whether the reference would have looked at the feature at all (its 10 kb
 // bucket-candidate rule) is decided on the device from left/right, see bulk.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "tecount_internal.h"
@@ -201,7 +202,16 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
             }
     }
     void* blob = nullptr;
-    TEC_HIP(ctx, hipMalloc(&blob, total));
+    {
+        // experiment knob: TEC_INDEX_MEM=uncached|finegrained allocates the index with that MTYPE
+        const char* m = getenv("TEC_INDEX_MEM");
+        if (m && !strcmp(m, "uncached"))
+            TEC_HIP(ctx, hipExtMallocWithFlags(&blob, total, hipDeviceMallocUncached));
+        else if (m && !strcmp(m, "finegrained"))
+            TEC_HIP(ctx, hipExtMallocWithFlags(&blob, total, hipDeviceMallocFinegrained));
+        else
+            TEC_HIP(ctx, hipMalloc(&blob, total));
+    }
     char* p = static_cast<char*>(blob);
     hipError_t e = hipMemcpy(p + o_off, bin_off.data(), (n_bins + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && n_entries_kept) e = hipMemcpy(p + o_ent, entries.data(), n_entries_kept * sizeof(tec_entry), hipMemcpyHostToDevice);
