@@ -229,6 +229,15 @@ const char* tec_bam_ref_name(const tec_bam* r, int i);
 int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int32_t* pos, int32_t* end, uint16_t* flag,
                  uint8_t* mapq, uint64_t* qkey, uint8_t* cb24, uint8_t* ub24, uint8_t* tagflags, uint64_t* n_out);
 
+/* ---- Dense single-cell TSV (the step after the path) ----------------------------------------
+ * Replaces the densifying loops of measureTE.sc_save_result (te_count.py:744-754).  header: the
+ * complete first line ('name\t<features...>\n'); labels: the row barcodes, '\0'-separated, in
+ * row order; row_cell[i]: barcode id of row i; coo_*: (barcode id, name id, count) sorted by
+ * (barcode, name) as tec_sc_fetch returns them.  Bytes identical to the reference's writer. */
+int tec_write_dense_tsv(const char* path, const char* header, uint64_t header_len, uint32_t n_names, uint32_t n_rows,
+                        const char* labels, const uint32_t* row_cell, uint64_t nnz, const uint32_t* coo_cell,
+                        const uint32_t* coo_name, const uint64_t* coo_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,3 +188,23 @@ def run_sc(features, records, whitelist, maxcells, quality_threshold=20, strand=
             os.chdir(cwd)
     return {'result': res, 'barcodes': list(m.barcodes.items()), 'total_reads': m.total_reads,
             'tsv': tsv, 'barcode_freq': freq}
+
+
+def run_make_custom(gtf_path):
+    """The reference's te_genome custom builder (te_count/genome/make.py:173-226) on a GTF file;
+    returns the feature rows of the index it writes."""
+    tc = load_reference()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'custom.glb')
+        stdout = sys.stdout
+        sys.stdout = io.StringIO()  # the builder prints progress bars
+        try:
+            tc.genome.make_custom(gtf_path, out, _quiet_log())
+        finally:
+            sys.stdout = stdout
+        gl = tc.miniglbase.glload(out)
+        rows = []
+        for r in gl.linearData:
+            rows.append({'chr': r['loc']['chr'], 'left': r['loc']['left'], 'right': r['loc']['right'],
+                         'strand': r['strand'], 'name': r['name'], 'type': r['type'], 'ensg': r['ensg']})
+    return rows

@@ -1,0 +1,105 @@
+"""Index builders (the reference's `te_genome`): GTF -> `.tecidx`.
+
+`make_custom` follows te_count/genome/make.py:173-226 over the reference's GTF reader
+(miniglbase/delayedlist.py:121-172, base_genelist.py:206-265): tab-separated columns without quote
+handling, `#` comment lines and a fixed list of header words skipped, attribute column split on
+"; " then shell-lexed (the LAST attribute keeps its trailing ';'), values coerced
+float > int > str, exons only, chromosomes X, Y, 1..29 after the index-side normalisation.
+The prepackaged modes (genes_tes, enhancers, snrnps) need network downloads
+(make.py:41-43) and are not built here; `make_genes_tes` accepts local copies of the two files.
+"""
+
+import csv
+import gzip
+import shlex
+
+from .index import FlatIndex, index_chrom_key
+
+# delayedlist.py:30-36
+TYPICAL_HEADERS = frozenset(["chipseq_loc", "loc", "chr", "#", "Gene Name", "", "GenBank", "RefSeq", "Systematic",
+                             "mm8.refGene.chrom", "mm8", "loc", 'chromosome', "mm9.refGene.chrom", "mm9",
+                             "=" * 70, "=" * 69, "=" * 71])
+
+CHR_SET_CUSTOM = frozenset(['X', 'Y'] + ['%s' % i for i in range(1, 30)])          # make.py:181
+CHR_SET_GENES_TES = frozenset(['X', 'Y', 'M'] + ['%s' % i for i in range(1, 30)])  # make.py:50
+
+
+def _guess(value):
+    """base_genelist.py:206-238: float if it has a '.' or an 'e' and parses, else int, else str."""
+    try:
+        if "." in value or 'e' in value:
+            return float(value)
+        raise ValueError
+    except ValueError:
+        try:
+            return int(value)
+        except ValueError:
+            return str(value).strip()
+
+
+def _unquote(v):
+    # delayedlist.py:159-165: csv quoting is off, so enclosing quotes are stripped by hand
+    if isinstance(v, str) and v:
+        if v[0] == "'" and v[-1] == "'":
+            v = v.strip("'")
+        if v and v[0] == '"' and v[-1] == '"':
+            v = v.strip('"')
+    return v
+
+
+def iter_gtf(path):
+    """Yields one dict per GTF row as the reference's delayedlist + gtf_format would
+    (make.py:8-10): feature_type, feature, strand, loc=(chr key, left, right), + attributes."""
+    opener = gzip.open if '.gz' in path else open
+    with opener(path, 'rt') as fh:
+        for column in csv.reader(fh, dialect=csv.excel_tab, quoting=csv.QUOTE_NONE):
+            if not column:
+                continue
+            if column[0][0:1] == '#' or column[0] in TYPICAL_HEADERS:
+                continue
+            # key order of gtf_format (make.py:8-10): attributes land between `feature` and `loc`,
+            # so a `loc` / `strand` attribute is overwritten by the column, a `feature` one wins
+            d = {'feature_type': _guess(column[1]), 'feature': _guess(column[2])}
+            for item in column[8].strip().split("; "):
+                if item:
+                    ss = shlex.split(item.strip())
+                    d[ss[0]] = _guess(ss[1].strip('"'))
+            d['loc'] = {'chr': index_chrom_key(column[0]), 'left': int(column[3]), 'right': int(column[4])}
+            d['strand'] = _guess(column[6])
+            for k in d:
+                if k != 'loc':
+                    d[k] = _unquote(d[k])
+            yield d
+
+
+def custom_features(gtffilename, log=None):
+    """make_custom's feature rows (make.py:184-218)."""
+    if log:
+        log.info('Checking GTF format')
+    for idx, item in enumerate(iter_gtf(gtffilename)):
+        assert 'ensg' in item, 'the custom GTF must have an "ensg" key that is unique and can be used to score expression'
+        assert 'gene_type' in item, 'the custom GTF must have a "gene_type" key, which should be one of "protein_coding/lncRNA"'
+        assert 'gene_id' in item, 'the custom GTF must have a "gene_id" key, which should contain a unqie identifier for the gene'
+        if idx > 10:
+            break
+    if log:
+        log.info('Processing custom gtf {0}'.format(gtffilename))
+    feats = []
+    for item in iter_gtf(gtffilename):
+        if item['feature'] != 'exon':
+            continue
+        if item['loc']['chr'] not in CHR_SET_CUSTOM:
+            continue
+        feats.append({'chr': item['loc']['chr'], 'left': item['loc']['left'], 'right': item['loc']['right'],
+                      'strand': item['strand'], 'name': item['gene_name'], 'type': item['gene_type'],
+                      'ensg': item['gene_id']})
+    return feats
+
+
+def make_custom(gtffilename, filename_for_index, log=None):
+    """te_count/genome/make.py:173-226 -> `.tecidx`."""
+    feats = custom_features(gtffilename, log)
+    print('\nAdded {:,} features'.format(len(feats)))
+    out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
+    FlatIndex.from_features(feats).save(out)
+    return out

@@ -10,10 +10,14 @@ import os
 
 import numpy as np
 
+import ctypes
+
+from . import _lib
 from . import reads as _reads
 from .bam import NO_END
 from .engine import Engine
 from .index import FlatIndex
+from .scresult import ScResult
 
 
 class _NullLog:
@@ -206,12 +210,10 @@ class measureTE:
         log.info('Part 3: Mapping the remaining UMIs to features')
 
         names = self.all_feature_names
-        final_results = {n: {} for n in names}
         for b, h in zip(out['cells'].tolist(), out['cell_hits'].tolist()):
             self.barcodes[whitelist[b]] = h
-        cc, cn, cv = out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()
-        for c, n, v in zip(cc, cn, cv):
-            final_results[names[n]][whitelist[c]] = v
+        final_results = ScResult(names, whitelist, out['coo_cell'], out['coo_name'], out['coo_count'])
+        self._barcode_id = {whitelist[b]: b for b in out['cells'].tolist()}
         log.info('  In the total pipeling, processed {:,} SE reads'.format(self.total_reads))
         log.info('  {:,} invalid barcode reads'.format(st['invalid_barcode']))
         log.info('  {:,} Read quality is too low (<{})'.format(st['lowq'], self.quality_threshold))
@@ -245,6 +247,18 @@ class measureTE:
                 oh.write('{0}\t{1}\n'.format(b, self.barcodes[b]))
         log.info('Saving barcode read frequency file to {0}'.format(freq_filename))
         features = list(result.keys())
+        if isinstance(result, ScResult) and all(b in getattr(self, '_barcode_id', {}) for b in cells):
+            # native writer over the GPU's triplets (same bytes; include/tecount.h tec_write_dense_tsv)
+            header = '{}\t{}\n'.format('name', '\t'.join(features)).encode()
+            labels = b''.join(b.encode() + b'\0' for b in cells)
+            row_cell = np.array([self._barcode_id[b] for b in cells], np.uint32)
+            lib = _lib.load()
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+            rc = lib.tec_write_dense_tsv(out_filename.encode(), header, len(header), len(features), len(cells), labels,
+                                         p(row_cell), len(result.coo_cell), p(result.coo_cell), p(result.coo_name),
+                                         p(result.coo_count))
+            _lib.check(None, rc)
+            return
         with open(out_filename, 'w') as oh:
             oh.write('{}\t{}\n'.format('name', '\t'.join(features)))
             for b in cells:

@@ -156,3 +156,28 @@ def make_sc_records(seed, n, whitelist, features=None, span=200000, n_cells=12, 
         if cursors[gi] == len(g):
             live.remove(gi)
     return recs[:n] if len(recs) > n else recs
+
+
+def make_gtf_text(seed, n_genes=40):
+    """A GTF with the quirks the reference's reader cares about: comment lines, non-exon rows,
+    contigs outside chr1-29/X/Y, dotted / numeric-looking ids, quoted and unquoted values, a
+    trailing ';' on the last attribute, extra attributes."""
+    rng = random.Random(seed)
+    lines = ['##description: synthetic', '#!genome-build test']
+    chroms = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chrUn_KI270742v1', 'chr1_KI270706v1_random', 'chr7', '12']
+    types = ['lncRNA', 'protein_coding', 'lincRNA', 'snRNA', 'miRNA']
+    for g in range(n_genes):
+        c = rng.choice(chroms)
+        start = rng.randrange(1, 150000)
+        gid = rng.choice(['ENSG%011d.%d' % (g, rng.randrange(1, 9)), 'ENH%07d' % g, 'gene_%d' % g, '%d' % (1000 + g)])
+        gname = rng.choice(['Gene%d' % g, 'GENE-%d' % g, 'G%d.1' % g])
+        gtype = rng.choice(types)
+        strand = rng.choice('+-')
+        attrs = 'gene_id "%s"; gene_type "%s"; gene_name "%s"; ensg "%s"; level %d; tag "basic";' % (
+            gid, gtype, gname, gid, rng.randrange(1, 4))
+        lines.append('\t'.join([c, 'SYN', 'gene', str(start), str(start + 5000), '.', strand, '.', attrs]))
+        for e in range(rng.randrange(1, 5)):
+            s = start + rng.randrange(0, 4000)
+            lines.append('\t'.join([c, 'SYN', rng.choice(['exon', 'exon', 'exon', 'CDS']), str(s), str(s + rng.randrange(1, 900)),
+                                    '.', strand, '.', attrs.replace('level', 'exon_number %d; level' % (e + 1))]))
+    return '\n'.join(lines) + '\n'

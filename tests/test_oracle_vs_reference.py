@@ -33,3 +33,11 @@ def test_sc_live(seed, strand, thr):
     assert res == ref['result'] and total == ref['total_reads']
     assert list(bcs.items()) == ref['barcodes']
     assert orc.format_sc_tsv(res, bcs, 6) == (ref['tsv'], ref['barcode_freq'])
+
+
+@pytest.mark.parametrize('seed', [5, 6])
+def test_custom_gtf_live(seed, tmp_path):
+    from te_counter_amd import genome
+    p = tmp_path / 'x.gtf'
+    p.write_text(dg.make_gtf_text(seed, 50))
+    assert genome.custom_features(str(p)) == rh.run_make_custom(str(p))
