@@ -53,10 +53,18 @@ def main():
     import torch.distributed as dist
     from te_counter_amd import Engine, synth
 
+    # one process per GPU; TEC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
+    # ranks (ranks then share devices and the reduce goes through gloo instead of RCCL)
+    backend = os.environ.get('TEC_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))  # nccl == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     paired = args.layout == 'pe'
     n_units = args.records // 2 if paired else args.records
@@ -129,7 +137,8 @@ def main():
                                    '%d records/GPU/step, %s order, -q 20' % (args.layout.upper(), args.genome, len(ann.flat),
                                                                             ann.flat.n_names, n_units * rec_per_unit, args.order),
                        'records_per_gpu_per_step': n_units * rec_per_unit, 'units_per_launch': n_units,
-                       'index': info, 'parallelism': 'dp%d' % world, 'collective': 'rccl all_reduce(sum) of u64 counts' if world > 1 else 'none',
+                       'index': info, 'parallelism': 'dp%d' % world,
+                       'collective': ('%s all_reduce(sum) of u64 counts' % ('rccl' if backend == 'nccl' else backend)) if world > 1 else 'none',
                        'setup_s': round(t_setup, 1)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic_for(args, n_units),
