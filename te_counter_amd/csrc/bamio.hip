@@ -417,6 +417,7 @@ extern "C" int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int3
         r->n_records += o;
         return TEC_OK;
     }
+    std::vector<size_t> offs;
     while (o < max_records) {
         int rc;
         if (!ensure(r, 4, &rc)) {
@@ -424,41 +425,74 @@ extern "C" int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int3
             if (r->buf.size() - r->buf_pos != 0) return bam_fail(r, TEC_EINVAL, "truncated BAM record");
             break;
         }
-        const uint32_t bs = le32(r->buf.data() + r->buf_pos);
-        if (bs < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
-        if (!ensure(r, 4 + (size_t)bs, &rc)) return bam_fail(r, rc ? rc : TEC_EINVAL, "truncated BAM record");
-        const uint8_t* p = r->buf.data() + r->buf_pos + 4;
-        const uint8_t* e = p + bs;
-        const int32_t refid = (int32_t)le32(p);
-        const int32_t p0 = (int32_t)le32(p + 4);
-        const unsigned l_name = p[8];
-        const unsigned n_cig = le16(p + 12);
-        const uint32_t l_seq = le32(p + 16);
-        const uint8_t* name = p + 32;
-        const uint8_t* cig = name + l_name;
-        const uint8_t* aux = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
-        if (aux > e) return bam_fail(r, TEC_EINVAL, "corrupt BAM record layout");
-        int64_t reflen = 0;
-        for (unsigned k = 0; k < n_cig; ++k) {
-            const uint32_t c = le32(cig + 4 * k);
-            const unsigned op = c & 15u;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += c >> 4;  // M D N = X
+        const uint32_t bs0 = le32(r->buf.data() + r->buf_pos);
+        if (bs0 < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
+        if (!ensure(r, 4 + (size_t)bs0, &rc)) return bam_fail(r, rc ? rc : TEC_EINVAL, "truncated BAM record");
+        // phase 1 (sequential, cheap): boundaries of the complete records already inflated
+        offs.clear();
+        size_t pos_b = r->buf_pos;
+        const size_t have = r->buf.size();
+        while (o + offs.size() < max_records && pos_b + 4 <= have) {
+            const uint32_t bs = le32(r->buf.data() + pos_b);
+            if (bs < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
+            if (pos_b + 4 + (size_t)bs > have) break;
+            offs.push_back(pos_b);
+            pos_b += 4 + (size_t)bs;
         }
-        tid[o] = refid;
-        pos[o] = p0;
-        end[o] = n_cig ? (int32_t)(p0 + reflen) : INT32_MIN;  // pysam: reference_end is None without a CIGAR
-        flag[o] = le16(p + 14);
-        mapq[o] = p[9];
-        if (qkey) qkey[o] = mate_key_hash((const char*)name, l_name ? l_name - 1 : 0);
-        if (tagflags) {
-            uint8_t tf = 0;
-            memset(cb24 + 24 * o, 0, 24);
-            memset(ub24 + 24 * o, 0, 24);
-            scan_aux(aux, e, cb24 + 24 * o, ub24 + 24 * o, &tf);
-            tagflags[o] = tf;
+        // phase 2 (parallel): field extraction into the SoA rows
+        const size_t nrec = offs.size();
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)r->n_threads, nrec / 4096));
+        std::vector<int> bad(nt, 0);
+        auto work = [&](int t) {
+            for (size_t k = (size_t)t; k < nrec; k += (size_t)nt) {
+                const uint8_t* p = r->buf.data() + offs[k] + 4;
+                const uint32_t bs = le32(p - 4);
+                const uint8_t* e = p + bs;
+                const uint64_t w = o + k;
+                const int32_t refid = (int32_t)le32(p);
+                const int32_t p0 = (int32_t)le32(p + 4);
+                const unsigned l_name = p[8];
+                const unsigned n_cig = le16(p + 12);
+                const uint32_t l_seq = le32(p + 16);
+                const uint8_t* name = p + 32;
+                const uint8_t* cig = name + l_name;
+                const uint8_t* aux = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
+                if (aux > e) {
+                    bad[t] = 1;
+                    return;
+                }
+                int64_t reflen = 0;
+                for (unsigned c = 0; c < n_cig; ++c) {
+                    const uint32_t v = le32(cig + 4 * c);
+                    const unsigned op = v & 15u;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;  // M D N = X
+                }
+                tid[w] = refid;
+                pos[w] = p0;
+                end[w] = n_cig ? (int32_t)(p0 + reflen) : INT32_MIN;  // pysam: reference_end is None without a CIGAR
+                flag[w] = le16(p + 14);
+                mapq[w] = p[9];
+                if (qkey) qkey[w] = mate_key_hash((const char*)name, l_name ? l_name - 1 : 0);
+                if (tagflags) {
+                    uint8_t tf = 0;
+                    memset(cb24 + 24 * w, 0, 24);
+                    memset(ub24 + 24 * w, 0, 24);
+                    scan_aux(aux, e, cb24 + 24 * w, ub24 + 24 * w, &tf);
+                    tagflags[w] = tf;
+                }
+            }
+        };
+        if (nt == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
         }
-        r->buf_pos += 4 + (size_t)bs;
-        ++o;
+        for (int t = 0; t < nt; ++t)
+            if (bad[t]) return bam_fail(r, TEC_EINVAL, "corrupt BAM record layout");
+        o += nrec;
+        r->buf_pos = pos_b;
     }
     *n_out = o;
     r->n_records += o;
