@@ -97,6 +97,20 @@ struct Sink {
     }
 };
 
+// The record kernel's add: nothing but the LDS (or, for names that do not fit, global) atomic.
+template <bool ALL_LDS>
+struct FastSink {
+    uint32_t* lds;
+    uint32_t k_lds;
+    unsigned long long* counts;
+    __device__ __forceinline__ void add(uint32_t name) const {
+        if (ALL_LDS || name < k_lds)
+            atomicAdd(&lds[name >> 1], 1u << ((name & 1u) * 16u));
+        else
+            atomicAdd(&counts[name], 1ull);
+    }
+};
+
 // Walks the hits of one unit.  Lists [a0,a1) / [b0,b1) are non-empty; ea / eb are their
 // prefetched first entries.  COUNT: add 1 to every distinct hit name.  Returns the OR of
 // (1 << class) over all hits (0 = no hit).
@@ -400,7 +414,7 @@ __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const tec_entry
     }
 }
 
-template <bool MIXED, int U, int NE>
+template <bool MIXED, int U, int NE, bool ALL_LDS>
 __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
                                                                const int32_t* __restrict__ p1,
                                                                const int32_t* __restrict__ p2,
@@ -414,8 +428,10 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     __syncthreads();
-    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};
-    unsigned sinkhole = 0;  // keeps ablated loads alive (TEC_ABLATE diagnostics)
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};  // exact path only
+    const FastSink<ALL_LDS> fast{hist, k_lds, counts};
+    const bool mute = (flags & 2u) != 0;  // TEC_ABLATE diagnostics
+    unsigned sinkhole = 0;                // keeps ablated loads alive (TEC_ABLATE diagnostics)
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     uint32_t since_flush = 0;
@@ -524,10 +540,15 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
                 if (hs.classes & (1u << TEC_CLASS_ENHANCER)) ++n_enh;
                 continue;
             }
-            sink.add(hs.h0);
-            if (hs.n > 1) sink.add(hs.h1);
-            if (hs.n > 2) sink.add(hs.h2);
-            if (hs.n > 3) sink.add(hs.h3);
+            if (mute) continue;
+            fast.add(hs.h0);
+            if (hs.n > 1) {
+                fast.add(hs.h1);
+                if (hs.n > 2) {
+                    fast.add(hs.h2);
+                    if (hs.n > 3) fast.add(hs.h3);
+                }
+            }
         }
     }
     flush_hist(hist, words, counts);
@@ -552,17 +573,22 @@ typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, co
                                uint64_t, uint32_t);
 
 template <int U>
-count_kernel_t pick_mixed(bool mixed, int rec_ne) {
-    if (rec_ne == 3) return mixed ? count_bulk_rec_kernel<true, U, 3> : count_bulk_rec_kernel<false, U, 3>;
-    if (rec_ne == 7) return mixed ? count_bulk_rec_kernel<true, U, 7> : count_bulk_rec_kernel<false, U, 7>;
+count_kernel_t pick_rec(bool mixed, bool all_lds) {
+    if (all_lds) return mixed ? count_bulk_rec_kernel<true, U, 3, true> : count_bulk_rec_kernel<false, U, 3, true>;
+    return mixed ? count_bulk_rec_kernel<true, U, 3, false> : count_bulk_rec_kernel<false, U, 3, false>;
+}
+template <int U>
+count_kernel_t pick_csr(bool mixed) {
     return mixed ? count_bulk_kernel<true, U> : count_bulk_kernel<false, U>;
 }
-// rec_ne: inline entries per bin record (3 or 7), 0 = the CSR walk kernel
-count_kernel_t pick_kernel(bool mixed, int unroll, int rec_ne) {
+// rec_ne: inline entries per bin record (3), 0 = the CSR walk kernel; all_lds: every name has an
+// LDS counter
+count_kernel_t pick_kernel(bool mixed, int unroll, int rec_ne, bool all_lds) {
+    if (rec_ne == 3) return unroll == 1 ? pick_rec<1>(mixed, all_lds) : pick_rec<2>(mixed, all_lds);
     switch (unroll) {
-        case 1: return pick_mixed<1>(mixed, rec_ne);
-        case 4: return pick_mixed<4>(mixed, rec_ne);
-        default: return pick_mixed<2>(mixed, rec_ne);
+        case 1: return pick_csr<1>(mixed);
+        case 4: return pick_csr<4>(mixed);
+        default: return pick_csr<2>(mixed);
     }
 }
 
@@ -630,7 +656,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
-    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 ? ctx->rec_ne : 0), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
+    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
                        u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
                        (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate);
     TEC_HIP(ctx, hipGetLastError());
@@ -645,16 +671,16 @@ int tec_bulk_init(tec_ctx* ctx) {
     // 79 KiB of dynamic LDS per workgroup needs the opt-in above the 64 KiB default
     for (int mixed = 0; mixed < 2; ++mixed)
         for (int u : {1, 2, 4})
-            for (int rec : {0, 3, 7})
-                TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec)),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (int rec : {0, 3})
+                for (int all = 0; all < 2; ++all)
+                    TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec, all != 0)),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
     e = getenv("TEC_KERNEL");  // 1: CSR walk kernel, 2: bin-record kernel
     ctx->kernel_variant = e && atoi(e) == 1 ? 1 : 2;
-    e = getenv("TEC_REC_NE");  // inline entries per bin record: 3 (32-byte records) or 7 (64-byte)
-    ctx->rec_ne_wanted = e && atoi(e) == 7 ? 7 : 3;
+    ctx->rec_ne_wanted = 3;  // inline entries per bin record (32-byte records)
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 0;
     e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)
