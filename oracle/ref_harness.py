@@ -196,15 +196,45 @@ def run_make_custom(gtf_path):
     tc = load_reference()
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, 'custom.glb')
-        stdout = sys.stdout
+        stdout, stderr = sys.stdout, sys.stderr
         sys.stdout = io.StringIO()  # the builder prints progress bars
+        sys.stderr = io.StringIO()
         try:
             tc.genome.make_custom(gtf_path, out, _quiet_log())
         finally:
-            sys.stdout = stdout
+            sys.stdout, sys.stderr = stdout, stderr
         gl = tc.miniglbase.glload(out)
         rows = []
         for r in gl.linearData:
             rows.append({'chr': r['loc']['chr'], 'left': r['loc']['left'], 'right': r['loc']['right'],
                          'strand': r['strand'], 'name': r['name'], 'type': r['type'], 'ensg': r['ensg']})
     return rows
+
+
+def run_make_genes_tes(genome, gencode_gz, rmsk_gz):
+    """The reference's make_genes_tes (te_count/genome/make.py:15-127) on LOCAL copies of the two
+    files it would download: its module-level `os` is swapped for a proxy whose system() does
+    nothing and whose path.dirname() points at a scratch directory holding the files under the
+    names the function expects.  Returns the feature rows of the index it writes."""
+    import shutil
+    tc = load_reference()
+    mk = sys.modules['te_count.genome.make']
+    names = {'mm10': 'gencode.vM23.annotation.gtf.gz', 'hg38': 'gencode.v42.annotation.gtf.gz',
+             'macFas5': 'Macaca_fascicularis.Macaca_fascicularis_6.0.115.gtf.gz'}
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(gencode_gz, os.path.join(td, names[genome]))
+        shutil.copy(rmsk_gz, os.path.join(td, f'{genome}_rmsk.txt.gz'))
+        proxy = types.SimpleNamespace(system=lambda cmd: 0,
+                                      path=types.SimpleNamespace(dirname=lambda p: td, realpath=os.path.realpath))
+        real_os, stdout, stderr = mk.os, sys.stdout, sys.stderr
+        mk.os = proxy
+        sys.stdout = io.StringIO()
+        sys.stderr = io.StringIO()  # progress bars
+        try:
+            mk.make_genes_tes(genome, _quiet_log())
+        finally:
+            mk.os = real_os
+            sys.stdout, sys.stderr = stdout, stderr
+        gl = tc.miniglbase.glload(os.path.join(td, f'{genome}_genes_tes.glb'))
+        return [{'chr': r['loc']['chr'], 'left': r['loc']['left'], 'right': r['loc']['right'], 'strand': r['strand'],
+                 'name': r['name'], 'type': r['type'], 'ensg': r['ensg']} for r in gl.linearData]

@@ -103,3 +103,58 @@ def make_custom(gtffilename, filename_for_index, log=None):
     out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
     FlatIndex.from_features(feats).save(out)
     return out
+
+
+KEEP_TE_CLASSES = frozenset(['LINE', 'LTR', 'SINE', 'DNA', 'Retroposon', 'tRNA'])  # make.py:55
+GENE_BIOTYPES = ('protein_coding', 'lncRNA', 'lincRNA')                              # make.py:93-97
+
+
+def iter_rmsk(path):
+    """UCSC rmsk.txt(.gz) rows as the reference reads them (make.py:12-13 `rmsk_track_form`):
+    tab-separated, columns 5/6/7 = chrom/start/end, 9 = strand, 10/11/12 = repName/repClass/
+    repFamily.  The format has no `skiplines`, so the reference's reader drops the FIRST line of
+    the file as a header (delayedlist.py:203-204) -- mirrored."""
+    opener = gzip.open if '.gz' in path else open
+    with opener(path, 'rt') as fh:
+        reader = csv.reader(fh, dialect=csv.excel_tab, quoting=csv.QUOTE_NONE)
+        next(reader, None)
+        for column in reader:
+            if not column or column[0] in TYPICAL_HEADERS:
+                continue
+            yield {'loc': {'chr': index_chrom_key(column[5]), 'left': int(column[6]), 'right': int(column[7])},
+                   'strand': _unquote(_guess(column[9])), 'repName': _unquote(_guess(column[10])),
+                   'repClass': _unquote(_guess(column[11])), 'repFamily': _unquote(_guess(column[12]))}
+
+
+def genes_tes_features(genome, gencode_path, rmsk_path):
+    """make_genes_tes (make.py:15-127) over local copies of the GENCODE GTF and the UCSC rmsk table
+    (the reference downloads them).  macFas5 uses Ensembl's *_biotype attribute names."""
+    gene_label, tx_label = ('gene_biotype', 'transcript_biotype') if genome == 'macFas5' else ('gene_type', 'transcript_type')
+    feats = []
+    for item in iter_rmsk(rmsk_path):
+        if item['repClass'] not in KEEP_TE_CLASSES:
+            continue
+        if str(item['loc']['chr']) not in CHR_SET_GENES_TES:
+            continue
+        te_name = f"{item['repClass']}:{item['repFamily']}:{item['repName']}"
+        feats.append({'chr': item['loc']['chr'], 'left': item['loc']['left'], 'right': item['loc']['right'],
+                      'strand': item['strand'], 'name': te_name, 'type': 'TE', 'ensg': te_name})
+    for item in iter_gtf(gencode_path):
+        if item['feature'] != 'exon':
+            continue
+        if item[gene_label] not in GENE_BIOTYPES or item[tx_label] not in GENE_BIOTYPES:
+            continue
+        if item['loc']['chr'] not in CHR_SET_GENES_TES:
+            continue
+        gene_name = item['gene_name'] if 'gene_name' in item else item['gene_id']
+        feats.append({'chr': item['loc']['chr'], 'left': item['loc']['left'], 'right': item['loc']['right'],
+                      'strand': item['strand'], 'name': gene_name, 'type': item[gene_label],
+                      'ensg': item['gene_id'].split('.')[0]})
+    return feats
+
+
+def make_genes_tes(genome, gencode_path, rmsk_path, filename_for_index):
+    feats = genes_tes_features(genome, gencode_path, rmsk_path)
+    out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
+    FlatIndex.from_features(feats).save(out)
+    return out

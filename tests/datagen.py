@@ -181,3 +181,49 @@ def make_gtf_text(seed, n_genes=40):
             lines.append('\t'.join([c, 'SYN', rng.choice(['exon', 'exon', 'exon', 'CDS']), str(s), str(s + rng.randrange(1, 900)),
                                     '.', strand, '.', attrs.replace('level', 'exon_number %d; level' % (e + 1))]))
     return '\n'.join(lines) + '\n'
+
+
+def make_gencode_text(seed, n_genes=40):
+    """GENCODE-like GTF: genes, transcripts and exons with gene_type / transcript_type."""
+    rng = random.Random(seed)
+    lines = ['##description: synthetic gencode', '##provider: test']
+    chroms = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chrUn_KI270742v1', 'chr17']
+    gtypes = ['protein_coding', 'lncRNA', 'lincRNA', 'snRNA', 'processed_pseudogene', 'miRNA']
+    for g in range(n_genes):
+        c = rng.choice(chroms)
+        start = rng.randrange(1, 150000)
+        gid = 'ENSG%011d.%d' % (g, rng.randrange(1, 19))
+        gt = rng.choice(gtypes)
+        strand = rng.choice('+-')
+        named = rng.random() < 0.8
+        base = 'gene_id "%s"; gene_type "%s";%s level 2;' % (gid, gt, (' gene_name "GN%d";' % g) if named else '')
+        lines.append('\t'.join([c, 'HAVANA', 'gene', str(start), str(start + 6000), '.', strand, '.', base]))
+        for t in range(rng.randrange(1, 4)):
+            tt = rng.choice([gt, gt, 'retained_intron', 'protein_coding'])
+            tx = base.replace(' level', ' transcript_id "ENST%08d.%d"; transcript_type "%s"; level' % (g * 10 + t, t + 1, tt))
+            lines.append('\t'.join([c, 'HAVANA', 'transcript', str(start), str(start + 6000), '.', strand, '.', tx]))
+            for e in range(rng.randrange(1, 4)):
+                s = start + rng.randrange(0, 5000)
+                ex = tx.replace(' level', ' exon_number %d; exon_id "ENSE%08d.1"; level' % (e + 1, g * 100 + t * 10 + e))
+                lines.append('\t'.join([c, 'HAVANA', 'exon', str(s), str(s + rng.randrange(5, 700)), '.', strand, '.', ex]))
+    return '\n'.join(lines) + '\n'
+
+
+def make_rmsk_text(seed, n=300):
+    """UCSC rmsk.txt rows (17 tab-separated columns, no header)."""
+    rng = random.Random(seed)
+    classes = [('LINE', 'L1', 'L1Md_F2'), ('LINE', 'L2', 'L2a'), ('SINE', 'Alu', 'AluY'), ('SINE', 'B2', 'B3'),
+               ('LTR', 'ERVK', 'IAPEz-int'), ('DNA', 'hAT-Charlie', 'MER5A'), ('Retroposon', 'SVA', 'SVA_D'),
+               ('tRNA', 'tRNA', 'tRNA-Ser-TCA'), ('Simple_repeat', 'Simple_repeat', '(CA)n'), ('Low_complexity', 'Low_complexity', 'GA-rich'),
+               ('Satellite', 'centr', 'GSAT_MM'), ('rRNA', 'rRNA', '5S'), ('LTR?', 'LTR?', 'LTR90A'), ('snRNA', 'snRNA', 'U6')]
+    chroms = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chr4_GL456216_random', 'chrUn_JH584304', 'chr19']
+    lines = []
+    for i in range(n):
+        cl, fam, name = rng.choice(classes)
+        c = rng.choice(chroms)
+        s = rng.randrange(0, 180000)
+        e = s + rng.randrange(20, 6000)
+        lines.append('\t'.join(map(str, [585 + s // 131072, rng.randrange(200, 30000), rng.randrange(0, 300), rng.randrange(0, 80),
+                                         rng.randrange(0, 80), c, s, e, -rng.randrange(1, 10 ** 8), rng.choice('+-'), name, cl, fam,
+                                         rng.randrange(1, 500), rng.randrange(500, 6000), -rng.randrange(0, 900), i % 9])))
+    return '\n'.join(lines) + '\n'

@@ -170,6 +170,15 @@ def main():
         fh.write(gtf_text)
     dump('custom_gtf_rows', {'kind': 'gtf', 'gtf_file': 'custom_annotation.gtf', 'expected': {'rows': rh.run_make_custom(gtf_path)}})
 
+    # te_genome -m genes_tes from local files: GENCODE-like GTF + rmsk table and the reference's rows
+    with gzip.GzipFile(os.path.join(HERE, 'genes_tes_gencode.gtf.gz'), 'wb', mtime=0) as fh:
+        fh.write(dg.make_gencode_text(41, 50).encode())
+    with gzip.GzipFile(os.path.join(HERE, 'genes_tes_rmsk.txt.gz'), 'wb', mtime=0) as fh:
+        fh.write(dg.make_rmsk_text(41, 300).encode())
+    for genome in ('hg38', 'mm10'):
+        dump('genes_tes_rows_%s' % genome, {'kind': 'genes_tes', 'genome': genome, 'expected': {'rows': rh.run_make_genes_tes(
+            genome, os.path.join(HERE, 'genes_tes_gencode.gtf.gz'), os.path.join(HERE, 'genes_tes_rmsk.txt.gz'))}})
+
     # an index file written by the reference itself (a pickle): fixture for the .glb importer
     feats = dg.make_features(9, 200)
     rh.build_reference_index(feats, os.path.join(HERE, 'ref_built_index.glb'))

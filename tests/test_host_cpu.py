@@ -128,3 +128,16 @@ def test_custom_gtf_builder_matches_reference_rows(tmp_path):
     out = genome.make_custom(gtf, str(tmp_path / 'mygenome')) if len(usable) == len(rows) else None
     if out:
         assert FlatIndex.load(out).names == sorted(set(r['ensg'] for r in rows))
+
+
+@pytest.mark.parametrize('genome_name', ['hg38', 'mm10'])
+def test_genes_tes_builder_matches_reference_rows(genome_name):
+    """make_genes_tes (te_count/genome/make.py:15-127) from local files: same rows, same order as
+    the reference built from the same GENCODE-like GTF and rmsk table (incl. its first-line drop)."""
+    from conftest import GOLDEN_DIR
+    from te_counter_amd import genome
+    g = load_golden('genes_tes_rows_%s' % genome_name)
+    rows = genome.genes_tes_features(genome_name, os.path.join(GOLDEN_DIR, 'genes_tes_gencode.gtf.gz'),
+                                     os.path.join(GOLDEN_DIR, 'genes_tes_rmsk.txt.gz'))
+    assert rows == g['expected']['rows'] and len(rows) > 100
+    assert {r['type'] for r in rows} >= {'TE', 'protein_coding'}
