@@ -8,7 +8,7 @@
 // passes:
 //
 //   submit   filters (te_count.py:394-433): flags, mapq, CB|CR present, whitelist lookup (binary
-//            search over the sorted, byte-packed whitelist -> id = rank, te_count.py:338,418),
+//            lookup in the sorted, byte-packed whitelist -> id = rank, te_count.py:338,418),
 //            UB|UR present, '_'/'alt' chromosomes; order-preserving compaction of survivors
 //   part 1   stable LSD radix sort by (barcode id, UMI bytes) -> records of one key are adjacent
 //            and in file order.  Epochs ("bundles", te_count.py:377-390) are recovered exactly:
@@ -70,6 +70,8 @@ struct tec_sc_state {
     uint64_t bundle_keys = 10000000;
     uint32_t n_wl = 0, n_class = 0;
     dvec<uint64_t> wl;          // 3 words per barcode, big-endian packed, ascending
+    dvec<uint32_t> wl_table;    // open-addressing hash over wl: rank + 1, 0 = empty
+    uint32_t wl_mask = 0;
     dvec<int32_t> cls_chrom;    // read-side chromosome class -> index chrom id (-1: not in index)
     dvec<uint8_t> cls_skip;     // '_' or 'alt' in the read-side chromosome string
     // survivors, in file order
@@ -108,20 +110,26 @@ __device__ __forceinline__ uint64_t load_be64(const uint8_t* p) {
     return __builtin_bswap64(v);
 }
 
-// rank of the 24-byte key in the sorted whitelist, or -1
-__device__ __forceinline__ int wl_find(const uint64_t* __restrict__ wl, uint32_t n, uint64_t a, uint64_t b, uint64_t c) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        const uint64_t x = wl[3 * (size_t)mid], y = wl[3 * (size_t)mid + 1], z = wl[3 * (size_t)mid + 2];
-        const bool less = x < a || (x == a && (y < b || (y == b && z < c)));
-        if (less)
-            lo = mid + 1;
-        else
-            hi = mid;
+__host__ __device__ __forceinline__ uint64_t wl_hash(uint64_t a, uint64_t b, uint64_t c) {
+    uint64_t h = a * 0x9E3779B97F4A7C15ull;
+    h ^= (h >> 32) ^ (b * 0xC2B2AE3D27D4EB4Full);
+    h ^= (h >> 29) ^ (c * 0x165667B19E3779F9ull);
+    h *= 0xD6E8FEB86659FD93ull;
+    return h ^ (h >> 32);
+}
+
+// Whitelist membership and rank (te_count.py:412,418): open-addressing table over the packed,
+// sorted whitelist; table[slot] = rank + 1, 0 = empty.  ~1.3 probes instead of a 20-step search.
+__device__ __forceinline__ int wl_find(const uint64_t* __restrict__ wl, const uint32_t* __restrict__ table,
+                                       uint32_t mask, uint64_t a, uint64_t b, uint64_t c) {
+    uint32_t slot = (uint32_t)wl_hash(a, b, c) & mask;
+    for (;;) {
+        const uint32_t v = table[slot];
+        if (v == 0) return -1;
+        const size_t i = (size_t)(v - 1);
+        if (wl[3 * i] == a && wl[3 * i + 1] == b && wl[3 * i + 2] == c) return (int)i;
+        slot = (slot + 1) & mask;
     }
-    if (lo < n && wl[3 * (size_t)lo] == a && wl[3 * (size_t)lo + 1] == b && wl[3 * (size_t)lo + 2] == c) return (int)lo;
-    return -1;
 }
 
 __device__ __forceinline__ void wave_add(unsigned long long* ctr, bool pred) {
@@ -133,7 +141,8 @@ __device__ __forceinline__ void wave_add(unsigned long long* ctr, bool pred) {
 __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* __restrict__ cls,
                                  const uint16_t* __restrict__ flag, const uint8_t* __restrict__ mapq,
                                  const uint8_t* __restrict__ cb, const uint8_t* __restrict__ tagflags, int mapq_min,
-                                 const uint64_t* __restrict__ wl, uint32_t n_wl, const uint8_t* __restrict__ cls_skip,
+                                 const uint64_t* __restrict__ wl, const uint32_t* __restrict__ wl_table, uint32_t wl_mask,
+                                 const uint8_t* __restrict__ cls_skip,
                                  uint32_t n_class, uint32_t* live, uint32_t* bcid_out, unsigned long long* stat) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool qc = false, lowq = false, badbc = false, skipc = false, ok = false;
@@ -150,7 +159,7 @@ __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* _
             int id = -1;
             if (!(tf & 4u)) {  // bit 2: barcode longer than 24 bytes, cannot be on the whitelist
                 const uint8_t* p = cb + 24 * i;
-                id = wl_find(wl, n_wl, load_be64(p), load_be64(p + 8), load_be64(p + 16));
+                id = wl_find(wl, wl_table, wl_mask, load_be64(p), load_be64(p + 8), load_be64(p + 16));
             }
             if (id < 0) {
                 badbc = true;
@@ -505,7 +514,7 @@ inline unsigned bits_for(uint64_t max_value) {
 
 void sc_free(tec_sc_state* s) {
     if (!s) return;
-    s->wl.release(); s->cls_chrom.release(); s->cls_skip.release();
+    s->wl.release(); s->wl_table.release(); s->cls_chrom.release(); s->cls_skip.release();
     s->bcid.release(); s->u0.release(); s->u1.release(); s->u2.release(); s->rec.release();
     s->klass.release(); s->left.release(); s->rite.release(); s->stat.release();
     s->b_live.release(); s->b_scan.release(); s->b_bcid.release(); s->b_in.release(); s->tmp.release();
@@ -556,6 +565,20 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
     }
     SC_HIP(s->wl.reserve(packed.size()));
     SC_HIP(hipMemcpy(s->wl.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
+    {
+        uint64_t cap = 16;
+        while (cap < 2ull * n_whitelist) cap <<= 1;
+        std::vector<uint32_t> table(cap, 0u);
+        const uint32_t mask = (uint32_t)(cap - 1);
+        for (uint32_t i = 0; i < n_whitelist; ++i) {
+            uint32_t slot = (uint32_t)wl_hash(packed[3 * (size_t)i], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2]) & mask;
+            while (table[slot]) slot = (slot + 1) & mask;
+            table[slot] = i + 1;
+        }
+        SC_HIP(s->wl_table.reserve(cap));
+        SC_HIP(hipMemcpy(s->wl_table.p, table.data(), cap * 4, hipMemcpyHostToDevice));
+        s->wl_mask = mask;
+    }
     SC_HIP(s->cls_chrom.reserve(std::max<uint32_t>(n_class, 1)));
     SC_HIP(s->cls_skip.reserve(std::max<uint32_t>(n_class, 1)));
     if (n_class) {
@@ -601,7 +624,7 @@ extern "C" int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const
     SC_HIP(s->b_bcid.reserve(n));
     hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, (const int32_t*)(b + o_cls),
                        (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_mq), (const uint8_t*)(b + o_cb),
-                       (const uint8_t*)(b + o_tf), s->mapq_min, s->wl.p, s->n_wl, s->cls_skip.p, s->n_class, s->b_live.p,
+                       (const uint8_t*)(b + o_tf), s->mapq_min, s->wl.p, s->wl_table.p, s->wl_mask, s->cls_skip.p, s->n_class, s->b_live.p,
                        s->b_bcid.p, s->stat.p);
     int rc = scan_u32(ctx, s, s->b_live.p, s->b_scan.p, n, false, rocprim::plus<uint32_t>());
     if (rc) return rc;
