@@ -3,19 +3,24 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := $(wildcard te_counter_amd/csrc/*.hip)
 HDRS  := $(wildcard te_counter_amd/csrc/*.h) include/tecount.h
+OBJS  := $(patsubst te_counter_amd/csrc/%.hip,build/%.o,$(CSRC))
 LIB   := te_counter_amd/libtecount.so
+FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -Iinclude
 
 all: $(LIB) oracle
 
-$(LIB): $(CSRC) $(HDRS)
-	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-result \
-	    -Iinclude -o $@ $(CSRC) -lz -lpthread
+build/%.o: te_counter_amd/csrc/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(FLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB)
+	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

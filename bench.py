@@ -36,7 +36,7 @@ def main():
     ap.add_argument('--order', default='shuffled', choices=['shuffled', 'sorted'])
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the annotation (tests)')
     ap.add_argument('--bin-shift', type=int, default=0)
-    ap.add_argument('--cpu-sample', type=int, default=8_000_000, help='units timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=25_000_000, help='units timed on the CPU oracle (0 = skip)')
     ap.add_argument('--traffic', default=None, help='HBM bytes per launch from rocprofv3 --pmc passes; default: profiles/traffic.json entry of this workload')
     ap.add_argument('--host-stream', action='store_true', help='also time the pinned-host -> HBM -> kernel path (PCIe-inclusive; reported beside, never as value)')
     args = ap.parse_args()

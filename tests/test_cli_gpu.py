@@ -68,3 +68,60 @@ def test_script_and_refusals(tmp_path):
         cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom', '--sc', '-w', 'x'])
     with pytest.raises(SystemExit):            # genome not built: bin/te_count:89-92
         cli.main(['-i', aln, '-o', out, '-g', 'hg38', '-m', 'genes_tes'])
+
+
+def _tests_sh_fixture(tmp_path, types, with_strand=True, sc=False, seed=61):
+    """Index + BAM for one line of the reference's test/tests.sh (modes genes_tes / enhancers / snrnps)."""
+    import datagen as dg
+    from te_counter_amd.index import FlatIndex
+    feats = dg.make_features(seed, 300, types=types, with_strand=with_strand)
+    idx = str(tmp_path / 'idx.tecidx')
+    FlatIndex.from_features(feats).save(idx)
+    if sc:
+        wl = dg.make_whitelist(seed, 60)
+        recs = dg.make_sc_records(seed + 1, 1500, wl, feats, n_cells=8)
+        wlf = tmp_path / 'barcodes.txt'
+        wlf.write_text(''.join(b + '\n' for b in wl))
+    else:
+        wl, wlf = None, None
+        recs = [r for r in dg.make_records(seed + 1, 1500, feats, paired=True) if r['end'] > r['pos']]
+    aln = str(tmp_path / 'in.bam')
+    bam.write_bam(aln, ListSource(recs).reference_names, recs)
+    return feats, recs, wl, idx, aln, (str(wlf) if wlf else None)
+
+
+@pytest.mark.parametrize('se', [False, True])
+def test_tests_sh_snrnps_bulk(se, tmp_path):
+    """tests.sh: `te_count [-se] -i bulk.bam -g hg38 -m snrnps` -- snRNA features are counted in bulk."""
+    from oracle import te_oracle as orc
+    feats, recs, _, idx, aln, _ = _tests_sh_fixture(tmp_path, ['snRNA', 'snRNA', 'miRNA'])
+    out = str(tmp_path / 'o.tsv')
+    cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom'] + (['--se'] if se else []))
+    res, total, _ = orc.bulk_count(feats, recs, not se)
+    assert open(out).read() == orc.format_bulk_tsv(res, total) and sum(res.values()) > 0
+
+
+def test_tests_sh_enhancers_modes_crash_like_the_reference(tmp_path):
+    """tests.sh runs the `enhancers` index through bulk and --sc; the reference dies in both
+    (NameError in bulk, te_count.py:145-147; KeyError 'strand' in sc, te_count.py:661)."""
+    feats, recs, _, idx, aln, _ = _tests_sh_fixture(tmp_path, ['enhancer'], with_strand=False)
+    with pytest.raises(NameError):
+        cli.main(['-i', aln, '-o', str(tmp_path / 'o.tsv'), '-g', idx, '-m', 'custom'])
+    feats, recs, wl, idx, aln, wlf = _tests_sh_fixture(tmp_path, ['enhancer'], with_strand=False, sc=True)
+    with pytest.raises(KeyError):
+        cli.main(['-i', aln, '-o', str(tmp_path / 'c.tsv'), '-g', idx, '-m', 'custom', '--sc', '--se', '-w', wlf, '--maxcells', '3'])
+
+
+def test_tests_sh_sc_maxcells_3(tmp_path):
+    """tests.sh: `--se --sc ... --maxcells 3` with and without --strand; snRNA is not counted in sc."""
+    from oracle import te_oracle as orc
+    types = ['protein_coding', 'lncRNA', 'TE', 'TE', 'snRNA']
+    feats, recs, wl, idx, aln, wlf = _tests_sh_fixture(tmp_path, types, sc=True)
+    for strand in (False, True):
+        out = str(tmp_path / ('single_cell%s.tsv' % ('_strand' if strand else '')))
+        cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom', '--sc', '--se', '-w', wlf, '--maxcells', '3'] +
+                 (['--strand'] if strand else []))
+        res, bcs, _ = orc.sc_count(feats, recs, wl, 3, strand=strand)
+        tsv, freq = orc.format_sc_tsv(res, bcs, 3)
+        assert open(out).read() == tsv and tsv.count('\n') == 4
+        assert open(out.replace('.tsv', '.barcode_freq.tsv')).read() == freq
