@@ -25,8 +25,9 @@ constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
 constexpr uint32_t kCountable = (1u << TEC_CLASS_GENE) | (1u << TEC_CLASS_TE) | (1u << TEC_CLASS_SNRNA);
 constexpr uint32_t kNoName = 0xFFFFFFFFu;
 constexpr int kBlock = 1024;
-constexpr uint32_t kLdsBytes = 79 * 1024;      // per workgroup: two workgroups fit a CU's 160 KiB
-constexpr uint32_t kLdsMaxBytes = 158 * 1024;  // one workgroup per CU
+constexpr uint32_t kLdsBytes = 78 * 1024;      // per workgroup: two workgroups fit a CU's 160 KiB
+constexpr uint32_t kLdsMaxBytes = 156 * 1024;  // one workgroup per CU (room for the static chromosome table)
+constexpr uint32_t kChromLds = 256;            // chromosomes whose {base, bins} live in LDS
 
 // floor(x / 10000) for x >= -1 (one 32-bit multiply-high; negative -> -1).
 __device__ __forceinline__ int bucket_of(int x) { return x < 0 ? -1 : (int)((unsigned)x / (unsigned)TEC_BUCKET_SIZE); }
@@ -424,6 +425,11 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
                                                                unsigned long long* stats, uint32_t k_lds, uint64_t span,
                                                                uint32_t flags) {
     extern __shared__ uint32_t hist[];
+    // per-chromosome {first fine bin, bin count} in LDS: one dependent global gather less per unit
+    __shared__ uint2 chrom_tab[kChromLds];
+    const bool chrom_in_lds = idx.n_chrom <= kChromLds;
+    if (chrom_in_lds)
+        for (uint32_t c = threadIdx.x; c < idx.n_chrom; c += kBlock) chrom_tab[c] = make_uint2(idx.chrom_base[c], idx.chrom_nbins[c]);
     constexpr uint32_t chunk = U * kBlock;
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
@@ -484,7 +490,15 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
                 ++n_bad;
                 live[k] = false;
             } else {
-                const uint32_t nb = idx.chrom_nbins[ch[k]], cb = idx.chrom_base[ch[k]];
+                uint32_t nb, cb;
+                if (chrom_in_lds) {
+                    const uint2 t = chrom_tab[ch[k]];
+                    cb = t.x;
+                    nb = t.y;
+                } else {
+                    nb = idx.chrom_nbins[ch[k]];
+                    cb = idx.chrom_base[ch[k]];
+                }
                 const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
                 const bool va = un[k].p1 >= 0 && ba < nb, vb = un[k].p2 >= 0 && bb < nb;
                 one[k] = va && vb && ba == bb;  // both edges in one bin: its record answers both tests
@@ -674,7 +688,7 @@ int tec_bulk_init(tec_ctx* ctx) {
             for (int rec : {0, 3})
                 for (int all = 0; all < 2; ++all)
                     TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec, all != 0)),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)(kChromLds * sizeof(uint2))));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
@@ -686,7 +700,7 @@ int tec_bulk_init(tec_ctx* ctx) {
     e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)
     ctx->ablate = e ? (atoi(e) & 62) : 0;
     e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup
-    ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 158 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
+    ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 156 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
     e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
     ctx->span_div = e && atoi(e) > 0 ? atoi(e) : 8;
     return TEC_OK;
