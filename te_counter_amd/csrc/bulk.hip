@@ -380,18 +380,21 @@ __device__ __forceinline__ BinRec<NE> load_rec(const uint4* __restrict__ recs, u
 // the scalar unit is shared by the CU's four SIMDs -- profiles/r01b showed more SALU than VALU
 // instructions in this stage.
 struct HitSet {
-    uint32_t h0, h1, h2, h3, n, classes;
-    bool overflow;
+    uint32_t h0, h1, h2, h3, n, classes;  // n may exceed 4: then the unit goes to the exact walk
+    // FULL: compare with all four kept names (second record); else only with the most recent one:
+    // entries are name-sorted inside a record, so while the first record is being scanned an
+    // equal name can only be the previous accepted one.  New names are shifted in at h0.
+    template <bool MIXED, bool FULL>
     __device__ __forceinline__ void add_if(bool hit, uint32_t meta) {
         const uint32_t name = meta & kNameMask;
-        classes |= hit ? 1u << ((meta >> TEC_META_CLASS_SHIFT) & 7u) : 0u;
-        const bool fresh = hit & (h0 != name) & (h1 != name) & (h2 != name) & (h3 != name);
-        h0 = (fresh & (n == 0u)) ? name : h0;
-        h1 = (fresh & (n == 1u)) ? name : h1;
-        h2 = (fresh & (n == 2u)) ? name : h2;
-        h3 = (fresh & (n == 3u)) ? name : h3;
-        overflow |= fresh & (n >= 4u);
-        n += (fresh & (n < 4u)) ? 1u : 0u;
+        if (MIXED) classes |= hit ? 1u << ((meta >> TEC_META_CLASS_SHIFT) & 7u) : 0u;
+        bool fresh = hit & (h0 != name);
+        if (FULL) fresh = fresh & (h1 != name) & (h2 != name) & (h3 != name);
+        h3 = fresh ? h2 : h3;
+        h2 = fresh ? h1 : h2;
+        h1 = fresh ? h0 : h1;
+        h0 = fresh ? name : h0;
+        n += fresh ? 1u : 0u;
     }
 };
 
@@ -399,7 +402,7 @@ struct HitSet {
 // candidate, see is_candidate).  t1_on / t2_on: is p1 / p2 inside this record's bin?  x1 / x2 are
 // the positions relative to (bin start - 1).  Inline slots beyond the bin's count are zero and
 // fail both tests by themselves; entries beyond NE continue in the CSR list (absolute tests).
-template <int NE>
+template <int NE, bool MIXED, bool FULL>
 __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const tec_entry* __restrict__ ent, const Unit& u, int x1,
                                             int x2, bool t1_on, bool t2_on, HitSet& hs) {
 #pragma unroll
@@ -407,11 +410,11 @@ __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const tec_entry
         const int l = (int)(r.lr[k] & 0xFFFFu), g = (int)(r.lr[k] >> 16);
         const bool t1 = t1_on & (x1 >= l) & (x1 < g);
         const bool t2 = t2_on & (x2 > l) & (x2 <= g);
-        hs.add_if(t1 | t2, r.meta[k]);
+        hs.add_if<MIXED, FULL>(t1 | t2, r.meta[k]);
     }
     for (uint32_t k = NE; k < r.n; ++k) {
         const tec_entry e = ent[r.off + k];
-        hs.add_if(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
+        hs.add_if<MIXED, FULL>(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
     }
 }
 
@@ -524,14 +527,14 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
             const unsigned q2 = ((unsigned)u.p2 + 1u) / (unsigned)TEC_BUCKET_SIZE;
             u.boundary = u.p1 < 0 || u.p2 < 0 || u.p2 == 0x7FFFFFFF || (unsigned)u.p1 == q1 * TEC_BUCKET_SIZE ||
                          (unsigned)u.p2 + 1u == q2 * TEC_BUCKET_SIZE;
-            HitSet hs{kNoName, kNoName, kNoName, kNoName, 0u, 0u, false};
+            HitSet hs{kNoName, kNoName, kNoName, kNoName, 0u, 0u};
             if (!u.boundary) {
-                scan_record<NE>(ra[k], ent, u, xa1[k], xa2[k], true, one[k], hs);
-                scan_record<NE>(rb[k], ent, u, 0, xb2[k], false, true, hs);
+                scan_record<NE, MIXED, false>(ra[k], ent, u, xa1[k], xa2[k], true, one[k], hs);
+                scan_record<NE, MIXED, true>(rb[k], ent, u, 0, xb2[k], false, true, hs);
             }
             // exact CSR walk for the rare rest: p1 or p2+1 on a 10 kb boundary (the reference's
             // bucket-candidate rule can bite there), or more than four distinct names
-            if (u.boundary || hs.overflow) {
+            if (u.boundary || hs.n > 4u) {
                 uint32_t a0 = ra[k].off, a1 = ra[k].off + ra[k].n, b0 = rb[k].off, b1 = rb[k].off + rb[k].n;
                 if (ra[k].n == 0) { a0 = b0; a1 = b1; }
                 if (rb[k].n == 0) { b0 = a0; b1 = a1; }
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev id
                 }
                 continue;
             }
-            if (hs.classes == 0) continue;
+            if (hs.n == 0 && (!MIXED || hs.classes == 0)) continue;
             ++n_assigned;
             if (MIXED && !(hs.classes & kCountable)) {
                 if (hs.classes & (1u << TEC_CLASS_ENHANCER)) ++n_enh;
