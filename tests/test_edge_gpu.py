@@ -107,3 +107,25 @@ def test_sc_everything_filtered_raises_like_the_reference(tmp_path):
             m.sc_parse_bamse(ListSource(rs), whitelistfilename=str(wlf), label='x', maxcells=5)
         with pytest.raises(ZeroDivisionError):
             orc.sc_count(feats, rs, ['AAAA'], 5)
+
+
+def test_many_chromosomes():
+    """More chromosomes than the kernel keeps in LDS (custom GTFs with thousands of contigs)."""
+    rng = np.random.default_rng(9)
+    n_chrom, n_feat, n_units = 700, 20000, 300000
+    chrom = rng.integers(0, n_chrom, n_feat)
+    left = rng.integers(0, 50000, n_feat)
+    right = left + rng.integers(1, 3000, n_feat)
+    meta = (rng.integers(0, 500, n_feat) | (rng.integers(1, 4, n_feat) << 26)).astype(np.uint32)
+    flat = FlatIndex(['n%03d' % i for i in range(500)], ['c%d' % i for i in range(n_chrom)], ['+', '-'], chrom, left, right, meta)
+    uc = rng.integers(-1, n_chrom + 2, n_units).astype(np.int32)
+    p1 = rng.integers(0, 52000, n_units).astype(np.int32)
+    units = (uc, p1, (p1 + rng.integers(1, 400, n_units)).astype(np.int32), np.zeros(n_units, np.uint16), np.full(n_units, 255, np.uint8))
+    want, wst = c_oracle.COracleIndex.from_flat(flat).bulk_count(*units, 20)
+    eng = Engine(0)
+    eng.upload_index(flat)
+    eng.bulk_begin(20)
+    eng.bulk_submit(*units)
+    got, gst = eng.bulk_finish()
+    assert np.array_equal(got, want) and all(gst[k] == v for k, v in wst.items())
+    eng.close()
