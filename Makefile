@@ -5,7 +5,7 @@ CSRC  := $(wildcard te_counter_amd/csrc/*.hip)
 HDRS  := $(wildcard te_counter_amd/csrc/*.h) include/tecount.h
 OBJS  := $(patsubst te_counter_amd/csrc/%.hip,build/%.o,$(CSRC))
 LIB   := te_counter_amd/libtecount.so
-FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -Iinclude
+FLAGS := $(EXTRA) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -Iinclude
 
 all: $(LIB) oracle
 

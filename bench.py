@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--order', default='shuffled', choices=['shuffled', 'sorted'])
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the annotation (tests)')
     ap.add_argument('--bin-shift', type=int, default=0)
+    ap.add_argument('--genes', type=int, default=40000, help='genes in the synthetic annotation (experiments)')
     ap.add_argument('--cpu-sample', type=int, default=25_000_000, help='units timed on the CPU oracle (0 = skip)')
     ap.add_argument('--traffic', default=None, help='HBM bytes per launch from rocprofv3 --pmc passes; default: profiles/traffic.json entry of this workload')
     ap.add_argument('--host-stream', action='store_true', help='also time the pinned-host -> HBM -> kernel path (PCIe-inclusive; reported beside, never as value)')
@@ -71,7 +72,7 @@ def main():
     rec_per_unit = 2 if paired else 1
 
     t0 = time.time()
-    ann = synth.make_annotation(args.genome, scale=args.scale)
+    ann = synth.make_annotation(args.genome, scale=args.scale, n_genes=args.genes)
     eng = Engine(local)
     eng.upload_index(ann.flat, args.bin_shift)
     info = eng.index_info()

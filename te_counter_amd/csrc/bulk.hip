@@ -25,6 +25,9 @@ constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
 constexpr uint32_t kCountable = (1u << TEC_CLASS_GENE) | (1u << TEC_CLASS_TE) | (1u << TEC_CLASS_SNRNA);
 constexpr uint32_t kNoName = 0xFFFFFFFFu;
 constexpr int kBlock = 1024;
+#ifndef TEC_REC_WAVES
+#define TEC_REC_WAVES 4  // min waves per SIMD the record kernel is compiled for (8: two workgroups per CU)
+#endif
 constexpr uint32_t kLdsBytes = 78 * 1024;      // per workgroup: two workgroups fit a CU's 160 KiB
 constexpr uint32_t kLdsMaxBytes = 156 * 1024;  // one workgroup per CU (room for the static chromosome table)
 constexpr uint32_t kChromLds = 256;            // chromosomes whose {base, bins} live in LDS
@@ -419,7 +422,7 @@ __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const tec_entry
 }
 
 template <bool MIXED, int U, int NE, bool ALL_LDS>
-__global__ __launch_bounds__(kBlock) void count_bulk_rec_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
+__global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
                                                                const int32_t* __restrict__ p1,
                                                                const int32_t* __restrict__ p2,
                                                                const uint16_t* __restrict__ flag,
