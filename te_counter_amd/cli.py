@@ -90,6 +90,12 @@ def main(argv=None):
         log.info('Found {} genome {}'.format(args.genome[0], args.mode[0]))
 
     if args.sc:
+        if world.size > 1 and world.rank != 0:
+            # the single-cell path needs the file-order epoch boundaries: it runs on one GPU
+            # (DESIGN.md section 6); the other ranks of a multi-GPU launch stand by
+            log.info('single-cell mode runs on rank 0 only; rank {} is idle'.format(world.rank))
+            world.close()
+            return
         if args.se:
             result = mte.sc_parse_bamse(args.inbam[0], UMIS=not args.noumi, maxcells=args.maxcells,
                                         whitelistfilename=args.w, strand=args.strand, log=log,
