@@ -86,3 +86,45 @@ def test_custom_3M_interval_annotation():
         acc += _count(eng, [u[r::2] for u in units])[0]
     assert np.array_equal(acc, full)
     eng.close()
+
+
+def test_sc_batching_invariance_and_oracle_sample():
+    """Single-cell path at 6 M records (config 4 generator, several spill epochs): the result must
+    not depend on how the file is cut into batches; a 120 k-record run of the same generator is
+    checked bit-for-bit against the Python oracle."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from oracle import te_oracle as orc
+    import bench_sc
+    ann = synth.make_annotation('hg38', scale=0.05)
+    eng = Engine(0)
+    eng.upload_index(ann.flat)
+    arrays, wl, tables = synth.make_sc_arrays(ann, 6_000_000, n_cells=2000, n_whitelist=50000, seed=77)
+    outs = []
+    for batch in (1 << 20, 1 << 22, 1 << 23, 777_777):
+        out, st, _, (ids, counts) = bench_sc.run(eng, arrays, wl, tables, 1500, True, 400_000, batch=batch)
+        outs.append((out, st, ids, counts))
+    assert outs[0][1]['bundles'] >= 4
+    for o in outs[1:]:
+        assert o[1] == outs[0][1]
+        assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[3], outs[0][3])
+        for k in ('cells', 'cell_hits', 'coo_cell', 'coo_name', 'coo_count'):
+            assert np.array_equal(o[0][k], outs[0][0][k]), k
+    # oracle sample
+    small = synth.make_annotation('hg38', scale=0.01)
+    eng.upload_index(small.flat)
+    arrays, wl, tables = synth.make_sc_arrays(small, 120_000, n_cells=60, n_whitelist=3000, seed=78)
+    out, st, _, _ = bench_sc.run(eng, arrays, wl, tables, 20, False, 9000, batch=50_000)
+    wl_str = [bytes(r).rstrip(b'\0').decode() for r in wl]
+    f = small.flat
+    feats = [{'chr': f.chrom_keys[c], 'left': int(l), 'right': int(r), 'strand': '+-'[(m >> 29) & 1], 'name': 'x',
+              'type': 'TE' if ((m >> 26) & 7) == 2 else 'protein_coding', 'ensg': f.names[m & ((1 << 26) - 1)]}
+             for c, l, r, m in zip(f.chrom_id.tolist(), f.left.tolist(), f.right.tolist(), f.meta.tolist())]
+    want, wbc, _ = orc.sc_count(feats, synth.sc_arrays_to_records(arrays, tables[0]), wl_str, 20, strand=False, bundle_threshold=9000)
+    got = {}
+    for c, nm, v in zip(out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()):
+        got.setdefault(f.names[nm], {})[wl_str[c]] = v
+    assert got == {k: v for k, v in want.items() if v}
+    assert [(wl_str[c], h) for c, h in zip(out['cells'].tolist(), out['cell_hits'].tolist())] == list(wbc.items())
+    eng.close()
