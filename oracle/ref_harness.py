@@ -211,6 +211,30 @@ def run_make_custom(gtf_path):
     return rows
 
 
+def run_make_snrnps(genome, gencode_gz):
+    """The reference's make_snrnps (make.py:228-288) on a local GENCODE file (same os proxy as
+    run_make_genes_tes)."""
+    import shutil
+    tc = load_reference()
+    mk = sys.modules['te_count.genome.make']
+    names = {'mm10': 'gencode.vM23.annotation.gtf.gz', 'hg38': 'gencode.v42.annotation.gtf.gz'}
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(gencode_gz, os.path.join(td, names[genome]))
+        proxy = types.SimpleNamespace(system=lambda cmd: 0,
+                                      path=types.SimpleNamespace(dirname=lambda p: td, realpath=os.path.realpath))
+        real_os, stdout, stderr = mk.os, sys.stdout, sys.stderr
+        mk.os = proxy
+        sys.stdout, sys.stderr = io.StringIO(), io.StringIO()
+        try:
+            mk.make_snrnps(genome, _quiet_log())
+        finally:
+            mk.os = real_os
+            sys.stdout, sys.stderr = stdout, stderr
+        gl = tc.miniglbase.glload(os.path.join(td, f'{genome}_snrnps.glb'))
+        return [{'chr': r['loc']['chr'], 'left': r['loc']['left'], 'right': r['loc']['right'], 'strand': r['strand'],
+                 'name': r['name'], 'type': r['type'], 'ensg': r['ensg']} for r in gl.linearData]
+
+
 def run_make_genes_tes(genome, gencode_gz, rmsk_gz):
     """The reference's make_genes_tes (te_count/genome/make.py:15-127) on LOCAL copies of the two
     files it would download: its module-level `os` is swapped for a proxy whose system() does

@@ -158,3 +158,28 @@ def make_genes_tes(genome, gencode_path, rmsk_path, filename_for_index):
     out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
     FlatIndex.from_features(feats).save(out)
     return out
+
+
+def snrnps_features(gencode_path):
+    """make_snrnps (make.py:228-288) over a local GENCODE GTF.  The reference tests
+    `item['gene_type'] not in ('snRNA')` -- a SUBSTRING test against the string 'snRNA' (the
+    parentheses make no tuple), so e.g. a gene_type of 'RNA' passes too; mirrored."""
+    feats = []
+    for item in iter_gtf(gencode_path):
+        if item['feature'] != 'exon':
+            continue
+        if item['gene_type'] not in 'snRNA' or item['transcript_type'] not in 'snRNA':
+            continue
+        if item['loc']['chr'] not in CHR_SET_CUSTOM:
+            continue
+        feats.append({'chr': item['loc']['chr'], 'left': item['loc']['left'], 'right': item['loc']['right'],
+                      'strand': item['strand'], 'name': 'snRNA-' + item['gene_name'], 'type': item['gene_type'],
+                      'ensg': item['gene_id'].split('.')[0]})
+    return feats
+
+
+def make_snrnps(gencode_path, filename_for_index):
+    feats = snrnps_features(gencode_path)
+    out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
+    FlatIndex.from_features(feats).save(out)
+    return out

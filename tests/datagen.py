@@ -188,7 +188,7 @@ def make_gencode_text(seed, n_genes=40):
     rng = random.Random(seed)
     lines = ['##description: synthetic gencode', '##provider: test']
     chroms = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chrUn_KI270742v1', 'chr17']
-    gtypes = ['protein_coding', 'lncRNA', 'lincRNA', 'snRNA', 'processed_pseudogene', 'miRNA']
+    gtypes = ['protein_coding', 'lncRNA', 'lincRNA', 'snRNA', 'snRNA', 'processed_pseudogene', 'miRNA', 'RNA']
     for g in range(n_genes):
         c = rng.choice(chroms)
         start = rng.randrange(1, 150000)

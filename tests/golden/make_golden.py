@@ -179,6 +179,9 @@ def main():
         dump('genes_tes_rows_%s' % genome, {'kind': 'genes_tes', 'genome': genome, 'expected': {'rows': rh.run_make_genes_tes(
             genome, os.path.join(HERE, 'genes_tes_gencode.gtf.gz'), os.path.join(HERE, 'genes_tes_rmsk.txt.gz'))}})
 
+    dump('snrnps_rows_hg38', {'kind': 'snrnps', 'genome': 'hg38', 'expected': {'rows': rh.run_make_snrnps(
+        'hg38', os.path.join(HERE, 'genes_tes_gencode.gtf.gz'))}})
+
     # an index file written by the reference itself (a pickle): fixture for the .glb importer
     feats = dg.make_features(9, 200)
     rh.build_reference_index(feats, os.path.join(HERE, 'ref_built_index.glb'))

@@ -141,3 +141,13 @@ def test_genes_tes_builder_matches_reference_rows(genome_name):
                                      os.path.join(GOLDEN_DIR, 'genes_tes_rmsk.txt.gz'))
     assert rows == g['expected']['rows'] and len(rows) > 100
     assert {r['type'] for r in rows} >= {'TE', 'protein_coding'}
+
+
+def test_snrnps_builder_matches_reference_rows():
+    """make_snrnps (make.py:228-288), including its substring test `not in ('snRNA')`."""
+    from conftest import GOLDEN_DIR
+    from te_counter_amd import genome
+    g = load_golden('snrnps_rows_hg38')
+    rows = genome.snrnps_features(os.path.join(GOLDEN_DIR, 'genes_tes_gencode.gtf.gz'))
+    assert rows == g['expected']['rows'] and len(rows) > 5
+    assert all(r['name'].startswith('snRNA-') for r in rows)
