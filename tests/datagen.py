@@ -183,7 +183,7 @@ def make_gtf_text(seed, n_genes=40):
     return '\n'.join(lines) + '\n'
 
 
-def make_gencode_text(seed, n_genes=40):
+def make_gencode_text(seed, n_genes=40, named_frac=0.8):
     """GENCODE-like GTF: genes, transcripts and exons with gene_type / transcript_type."""
     rng = random.Random(seed)
     lines = ['##description: synthetic gencode', '##provider: test']
@@ -195,7 +195,7 @@ def make_gencode_text(seed, n_genes=40):
         gid = 'ENSG%011d.%d' % (g, rng.randrange(1, 19))
         gt = rng.choice(gtypes)
         strand = rng.choice('+-')
-        named = rng.random() < 0.8
+        named = rng.random() < named_frac
         base = 'gene_id "%s"; gene_type "%s";%s level 2;' % (gid, gt, (' gene_name "GN%d";' % g) if named else '')
         lines.append('\t'.join([c, 'HAVANA', 'gene', str(start), str(start + 6000), '.', strand, '.', base]))
         for t in range(rng.randrange(1, 4)):

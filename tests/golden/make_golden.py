@@ -179,8 +179,10 @@ def main():
         dump('genes_tes_rows_%s' % genome, {'kind': 'genes_tes', 'genome': genome, 'expected': {'rows': rh.run_make_genes_tes(
             genome, os.path.join(HERE, 'genes_tes_gencode.gtf.gz'), os.path.join(HERE, 'genes_tes_rmsk.txt.gz'))}})
 
+    with gzip.GzipFile(os.path.join(HERE, 'snrnps_gencode.gtf.gz'), 'wb', mtime=0) as fh:
+        fh.write(dg.make_gencode_text(43, 120, named_frac=1.0).encode())  # make_snrnps needs gene_name everywhere
     dump('snrnps_rows_hg38', {'kind': 'snrnps', 'genome': 'hg38', 'expected': {'rows': rh.run_make_snrnps(
-        'hg38', os.path.join(HERE, 'genes_tes_gencode.gtf.gz'))}})
+        'hg38', os.path.join(HERE, 'snrnps_gencode.gtf.gz'))}})
 
     # an index file written by the reference itself (a pickle): fixture for the .glb importer
     feats = dg.make_features(9, 200)

@@ -148,6 +148,6 @@ def test_snrnps_builder_matches_reference_rows():
     from conftest import GOLDEN_DIR
     from te_counter_amd import genome
     g = load_golden('snrnps_rows_hg38')
-    rows = genome.snrnps_features(os.path.join(GOLDEN_DIR, 'genes_tes_gencode.gtf.gz'))
+    rows = genome.snrnps_features(os.path.join(GOLDEN_DIR, 'snrnps_gencode.gtf.gz'))
     assert rows == g['expected']['rows'] and len(rows) > 5
     assert all(r['name'].startswith('snRNA-') for r in rows)
