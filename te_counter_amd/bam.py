@@ -28,7 +28,48 @@ class BamSource:
         n = self._lib.tec_bam_n_refs(self._h)
         self.reference_names = [self._lib.tec_bam_ref_name(self._h, i).decode() for i in range(n)]
 
-    def batches(self, want_tags=False):
+    def batches(self, want_tags=False, prefetch=2):
+        """Batches in file order.  With prefetch > 0 a reader thread decodes up to that many
+        batches ahead (tec_bam_read runs without the GIL), so decoding overlaps with the caller's
+        unit assembly and GPU submission."""
+        if prefetch <= 0:
+            yield from self._batches(want_tags)
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=prefetch)
+        stop = threading.Event()
+
+        def reader():
+            try:
+                for b in self._batches(want_tags):
+                    while not stop.is_set():
+                        try:
+                            q.put(b, timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as e:  # hand decoding errors to the consumer
+                q.put(e)
+
+        t = threading.Thread(target=reader, daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            t.join(timeout=5)
+
+    def _batches(self, want_tags=False):
         n = self.batch_size
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         while True:
