@@ -663,7 +663,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const int unroll = ctx->unroll;
     const uint64_t chunk = (uint64_t)unroll * kBlock;
     const uint64_t want = (n + chunk - 1) / chunk;
-    const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0;
+    const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0 || ctx->force_mixed;
     // LDS histogram: every name if that fits (two workgroups per CU up to 79 KiB each, else one
     // workgroup with up to 158 KiB); beyond that the coldest names spill to global atomics.
     uint32_t budget = ctx->lds_bytes;
@@ -698,6 +698,8 @@ int tec_bulk_init(tec_ctx* ctx) {
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
+    e = getenv("TEC_FORCE_MIXED");  // diagnostics: run the mixed-class kernel on any index
+    ctx->force_mixed = e && atoi(e) != 0;
     e = getenv("TEC_KERNEL");  // 1: CSR walk kernel, 2: bin-record kernel
     ctx->kernel_variant = e && atoi(e) == 1 ? 1 : 2;
     ctx->rec_ne_wanted = 3;  // inline entries per bin record (32-byte records)

@@ -80,6 +80,7 @@ struct tec_ctx {
     int unroll = 2;  // units carried per lane by the count kernel
     int aggregate = 0;
     int kernel_variant = 2;
+    bool force_mixed = false;
     int rec_ne_wanted = 3;  // inline entries per bin record asked for (TEC_REC_NE)
     int rec_ne = 0;         // ... of the resident index (0: no records, bin shift too wide)
     int ablate = 0;  // diagnostics (TEC_ABLATE)
