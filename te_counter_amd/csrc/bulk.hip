@@ -705,8 +705,14 @@ int tec_bulk_init(tec_ctx* ctx) {
     ctx->rec_ne_wanted = 3;  // inline entries per bin record (32-byte records)
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 0;
-    e = getenv("TEC_ABLATE");  // diagnostics only: 2 no counting, 4 no list walk, 8 no gathers (wrong results!)
+#ifdef TEC_DIAGNOSTICS
+    // ablation builds only (make EXTRA=-DTEC_DIAGNOSTICS): 2 no counting, 4 no tests, 8 no gathers --
+    // results are WRONG by construction, so a normal build ignores the variable
+    e = getenv("TEC_ABLATE");
     ctx->ablate = e ? (atoi(e) & 62) : 0;
+#else
+    ctx->ablate = 0;
+#endif
     e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup
     ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 156 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
     e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
