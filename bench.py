@@ -31,7 +31,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--records', type=int, default=125_000_000, help='BAM records per GPU per step')
-    ap.add_argument('--genome', default='hg38', choices=['hg38', 'mm10'])
+    ap.add_argument('--genome', default='hg38', choices=['hg38', 'mm10', 'custom3m'],
+                    help="custom3m: BASELINE config 5, 3 M unique-name intervals")
     ap.add_argument('--layout', default='pe', choices=['pe', 'se'])
     ap.add_argument('--order', default='shuffled', choices=['shuffled', 'sorted'])
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the annotation (tests)')
@@ -72,7 +73,10 @@ def main():
     rec_per_unit = 2 if paired else 1
 
     t0 = time.time()
-    ann = synth.make_annotation(args.genome, scale=args.scale, n_genes=args.genes)
+    if args.genome == 'custom3m':
+        ann = synth.make_custom_annotation(scale=args.scale)
+    else:
+        ann = synth.make_annotation(args.genome, scale=args.scale, n_genes=args.genes)
     eng = Engine(local)
     eng.upload_index(ann.flat, args.bin_shift)
     info = eng.index_info()
@@ -130,11 +134,11 @@ def main():
         avg_ms = kernel_ms / max(1, launches)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         out = {
-            'metric': 'Mreads/s overlap-counted (bulk %s %s genes_tes)' % (args.layout.upper(), args.genome),
+            'metric': 'Mreads/s overlap-counted (bulk %s %s %s)' % (args.layout.upper(), args.genome, 'custom' if args.genome == 'custom3m' else 'genes_tes'),
             'value': round(value, 2), 'unit': 'Mreads/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'int32 coords / u64 counts', 'data': 'synthetic',
-            'config': {'workload': 'bulk %s, synthetic %s genes_tes-like annotation (%d intervals, %d names), '
+            'config': {'workload': 'bulk %s, synthetic %s-like annotation (%d intervals, %d names), '
                                    '%d records/GPU/step, %s order, -q 20' % (args.layout.upper(), args.genome, len(ann.flat),
                                                                             ann.flat.n_names, n_units * rec_per_unit, args.order),
                        'records_per_gpu_per_step': n_units * rec_per_unit, 'units_per_launch': n_units,
