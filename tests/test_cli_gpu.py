@@ -125,3 +125,20 @@ def test_tests_sh_sc_maxcells_3(tmp_path):
         tsv, freq = orc.format_sc_tsv(res, bcs, 3)
         assert open(out).read() == tsv and tsv.count('\n') == 4
         assert open(out.replace('.tsv', '.barcode_freq.tsv')).read() == freq
+
+
+def test_se_record_without_cigar_raises_like_pysam_would(tmp_path):
+    """A mapped SE record without CIGAR has reference_end None in pysam; the reference dies in
+    `loc2+1` (te_count.py:223) with TypeError.  Filtered records of that kind are harmless."""
+    g = load_golden('bulk_se_rand11')
+    idx = str(tmp_path / 'i.tecidx')
+    flat_from_golden(g).save(idx)
+    ok = {'flag': 0, 'mapq': 255, 'qname': 'a', 'rname': 'chr1', 'pos': 100, 'end': 150}
+    nocigar_filtered = {'flag': 0x4, 'mapq': 255, 'qname': 'b', 'rname': 'chr1', 'pos': 100, 'end': 100}
+    nocigar_live = {'flag': 0, 'mapq': 255, 'qname': 'c', 'rname': 'chr1', 'pos': 100, 'end': 100}
+    aln = str(tmp_path / 'a.bam')
+    bam.write_bam(aln, ['chr1'], [ok, nocigar_filtered, ok])
+    cli.main(['-i', aln, '-o', str(tmp_path / 'o.tsv'), '-g', idx, '-m', 'custom', '--se'])
+    bam.write_bam(aln, ['chr1'], [ok, nocigar_live, ok])
+    with pytest.raises(TypeError):
+        cli.main(['-i', aln, '-o', str(tmp_path / 'o2.tsv'), '-g', idx, '-m', 'custom', '--se'])
