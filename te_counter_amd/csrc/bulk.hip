@@ -176,16 +176,23 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
+// Flush of the per-workgroup histogram.  Every wave drains its own outstanding LDS atomics before
+// the barrier (an explicit s_waitcnt: hipcc 7.2 was seen to omit it on one loop path of the U = 2
+// record kernel, and a late ds_add that lands between another lane's read and clear of the same
+// word is a lost update -- caught by tools/stress_determinism.py as 30 missing counts in ~2 % of
+// launches), and the read-and-clear is one atomic exchange, so even a stray add can only be
+// deferred to the next flush, never lost.
 __device__ __forceinline__ void flush_hist(uint32_t* hist, uint32_t words, unsigned long long* counts) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) {
-        const uint32_t v = hist[w];
+        const uint32_t v = atomicExch(&hist[w], 0u);
         if (v) {
-            hist[w] = 0;
             if (v & 0xFFFFu) atomicAdd(&counts[2 * w], (unsigned long long)(v & 0xFFFFu));
             if (v >> 16) atomicAdd(&counts[2 * w + 1], (unsigned long long)(v >> 16));
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
     constexpr uint32_t chunk = U * kBlock;
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 32u) ? 32u : 0u,
                     (flags & 16u) ? 32u : ((flags & 32u) ? 0xFFFFFFFFu : 0u)};
@@ -439,6 +447,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     constexpr uint32_t chunk = U * kBlock;
     const uint32_t words = (k_lds + 1u) >> 1;
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};  // exact path only
     const FastSink<ALL_LDS> fast{hist, k_lds, counts};
