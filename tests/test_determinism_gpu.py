@@ -41,3 +41,26 @@ def test_repeated_launches_are_identical(order):
     c, _ = eng.bulk_finish()
     assert np.array_equal(c, 7 * ref)
     eng.close()
+
+
+def test_sc_repeated_runs_are_identical():
+    """The single-cell pipeline (atomics, rocPRIM sorts, epoch search) must be run-to-run stable."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_sc
+    ann = synth.make_annotation('hg38', scale=0.05)
+    eng = Engine(0)
+    eng.upload_index(ann.flat)
+    arrays, wl, tables = synth.make_sc_arrays(ann, 3_000_000, n_cells=1500, n_whitelist=40000, seed=5, order='sorted')
+    ref = None
+    for rep in range(25):
+        out, st, _, (ids, counts) = bench_sc.run(eng, arrays, wl, tables, 1000, bool(rep % 2), 250_000, batch=1 << 20)
+        key = (rep % 2)
+        cur = (st, ids.tobytes(), counts.tobytes()) + tuple(out[k].tobytes() for k in ('cells', 'cell_hits', 'coo_cell', 'coo_name', 'coo_count'))
+        if ref is None:
+            ref = {}
+        if key not in ref:
+            ref[key] = cur
+        assert cur == ref[key], 'run %d differs' % rep
+    eng.close()
