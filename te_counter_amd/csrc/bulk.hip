@@ -32,6 +32,30 @@ constexpr uint32_t kLdsBytes = 78 * 1024;      // per workgroup: two workgroups 
 constexpr uint32_t kLdsMaxBytes = 156 * 1024;  // one workgroup per CU (room for the static chromosome table)
 constexpr uint32_t kChromLds = 256;            // chromosomes whose {base, bins} live in LDS
 
+// Diagnostic builds (make EXTRA=-DTEC_DIAGNOSTICS): wave 0 of every workgroup accumulates the
+// shader-clock cycles it spends per stage of the record kernel (with a full s_waitcnt at every
+// stage end, so the numbers are latencies, and the kernel is slower than the product build).
+#ifdef TEC_DIAGNOSTICS
+__device__ unsigned long long g_stage_clk[8];
+#define TEC_CLK_DECL unsigned long long clk_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long clk_t = __builtin_amdgcn_s_memtime()
+#define TEC_CLK(i)                                                     \
+    do {                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        clk_acc[i] += now__ - clk_t;                                   \
+        clk_t = now__;                                                 \
+    } while (0)
+#define TEC_CLK_STORE                                                                   \
+    do {                                                                                \
+        if (threadIdx.x == 0)                                                           \
+            for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&g_stage_clk[i__], clk_acc[i__]); \
+    } while (0)
+#else
+#define TEC_CLK_DECL
+#define TEC_CLK(i)
+#define TEC_CLK_STORE
+#endif
+
 // floor(x / 10000) for x >= -1 (one 32-bit multiply-high; negative -> -1).
 __device__ __forceinline__ int bucket_of(int x) { return x < 0 ? -1 : (int)((unsigned)x / (unsigned)TEC_BUCKET_SIZE); }
 
@@ -60,8 +84,30 @@ __device__ __forceinline__ bool test2(const tec_entry& e, const Unit& u) { retur
 
 // Where a hit is counted.  The k_lds hottest names (internal ids are ordered by expected hit
 // rate, see index.hip) live in a per-workgroup LDS histogram of packed 16-bit counters
-// (ds_add_u32 of 1 << 16*(id&1)); a workgroup flushes it to the 64-bit global vector before any
-// counter can reach 65536.  Colder names go straight to global 64-bit atomics.
+// (ds_add_rtn_u32 of n << 16*(id&1)); colder names go straight to global 64-bit atomics.
+//
+// The 16-bit counters are never flushed before the end of the launch.  Instead every add looks at
+// the value it replaced: the one add that carries out of its half sees it (old half + n > 0xFFFF)
+// and books 65536 on the name's global counter.  A carry out of the LOW half also lands in the
+// neighbour's HIGH half; the same adder books -1 for the neighbour (64-bit two's complement) and,
+// if that pushed the high half over as well, the neighbour's 65536.  Atomics on one LDS word are
+// totally ordered, so each carry is seen by exactly one adder under any interleaving, and
+// global + (final LDS halves) is exact -- with no barrier and no flush inside the loop.
+__device__ __noinline__ void wrap_account(unsigned long long* counts, uint32_t name, uint32_t old) {
+    atomicAdd(&counts[name], 65536ull);
+    if (!(name & 1u)) {
+        atomicAdd(&counts[name + 1u], ~0ull);  // the carry this add pushed into the neighbour's half
+        if ((old >> 16) == 0xFFFFu) atomicAdd(&counts[name + 1u], 65536ull);
+    }
+}
+__device__ __forceinline__ bool wrapped(uint32_t name, uint32_t old, uint32_t n) {
+    return ((old >> ((name & 1u) * 16u)) & 0xFFFFu) + n > 0xFFFFu;
+}
+__device__ __forceinline__ void lds_add(uint32_t* lds, unsigned long long* counts, uint32_t name, uint32_t n) {
+    const uint32_t old = atomicAdd(&lds[name >> 1], n << ((name & 1u) * 16u));
+    if (wrapped(name, old, n)) wrap_account(counts, name, old);
+}
+
 struct Sink {
     uint32_t* lds;
     uint32_t k_lds;
@@ -69,7 +115,7 @@ struct Sink {
     bool aggregate;  // coordinate-sorted batches: neighbouring lanes hit the same name
     __device__ __forceinline__ void add_n(uint32_t name, uint32_t n) const {
         if (name < k_lds)
-            atomicAdd(&lds[name >> 1], n << ((name & 1u) * 16u));
+            lds_add(lds, counts, name, n);
         else
             atomicAdd(&counts[name], (unsigned long long)n);
     }
@@ -102,16 +148,17 @@ struct Sink {
 };
 
 // The record kernel's add: nothing but the LDS (or, for names that do not fit, global) atomic.
+// It hands back the replaced word; the caller checks all of a unit's adds for carries together
+// (one wait for the LDS returns instead of one per add).
 template <bool ALL_LDS>
 struct FastSink {
     uint32_t* lds;
     uint32_t k_lds;
     unsigned long long* counts;
-    __device__ __forceinline__ void add(uint32_t name) const {
-        if (ALL_LDS || name < k_lds)
-            atomicAdd(&lds[name >> 1], 1u << ((name & 1u) * 16u));
-        else
-            atomicAdd(&counts[name], 1ull);
+    __device__ __forceinline__ uint32_t add(uint32_t name) const {
+        if (ALL_LDS || name < k_lds) return atomicAdd(&lds[name >> 1], 1u << ((name & 1u) * 16u));
+        atomicAdd(&counts[name], 1ull);
+        return 0u;  // never reads as a carry
     }
 };
 
@@ -176,7 +223,7 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
-// Flush of the per-workgroup histogram.  Every wave drains its own outstanding LDS atomics before
+// Final flush of the per-workgroup histogram (once per launch).  Every wave drains its own outstanding LDS atomics before
 // the barrier (an explicit s_waitcnt: hipcc 7.2 was seen to omit it on one loop path of the U = 2
 // record kernel, and a late ds_add that lands between another lane's read and clear of the same
 // word is a lost update -- caught by tools/stress_determinism.py as 30 missing counts in ~2 % of
@@ -224,18 +271,11 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
     unsigned sinkhole = 0;  // keeps ablated loads alive
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
-    uint32_t since_flush = 0;
     // A workgroup owns spans of consecutive chunks, `gridDim.x` spans apart: at any moment the
     // workgroups are spread over the batch (for coordinate-sorted input: over the genome, so
     // that they do not all pull the same index lines through one L2 channel).
     for (uint64_t s0 = (uint64_t)blockIdx.x * span; s0 < n; s0 += (uint64_t)gridDim.x * span)
     for (uint64_t base = s0; base < n && base < s0 + span; base += chunk) {
-        if (since_flush + chunk > 65535u) {  // a 16-bit counter gains at most 1 per unit
-            flush_hist(hist, words, counts);
-            since_flush = 0;
-        }
-        since_flush += chunk;
-
         // ---- stage 1
         unsigned fl[U], mq[U];
         int ch[U];
@@ -385,14 +425,16 @@ __device__ __forceinline__ BinRec<NE> load_rec(const uint4* __restrict__ recs, u
     return r;
 }
 
-// The distinct hit names of one unit in four registers.  Almost every unit hits at most four
-// names; one that overflows is redone by the exact CSR walk (walk_hits).  Written without
-// branches (selects only): on CDNA every divergent `if` costs scalar exec-mask bookkeeping, and
-// the scalar unit is shared by the CU's four SIMDs -- profiles/r01b showed more SALU than VALU
-// instructions in this stage.
+// The distinct hit names of one unit in six registers.  0.5 % of the hg38-like units hit more
+// than four names -- a third of all wave trips would then take the exact walk with its chain of
+// dependent gathers -- but only 0.004 % hit more than six; those are redone by the exact CSR walk
+// (walk_hits).  Written without branches (selects only): on CDNA every divergent `if` costs
+// scalar exec-mask bookkeeping, and the scalar unit is shared by the CU's four SIMDs --
+// profiles/r01b showed more SALU than VALU instructions in this stage.
+constexpr uint32_t kHitSlots = 6;
 struct HitSet {
-    uint32_t h0, h1, h2, h3, n, classes;  // n may exceed 4: then the unit goes to the exact walk
-    // FULL: compare with all four kept names (second record); else only with the most recent one:
+    uint32_t h0, h1, h2, h3, h4, h5, n, classes;  // n may exceed kHitSlots: then the unit goes to the exact walk
+    // FULL: compare with all kept names (second record); else only with the most recent one:
     // entries are name-sorted inside a record, so while the first record is being scanned an
     // equal name can only be the previous accepted one.  New names are shifted in at h0.
     template <bool MIXED, bool FULL>
@@ -400,7 +442,9 @@ struct HitSet {
         const uint32_t name = meta & kNameMask;
         if (MIXED) classes |= hit ? 1u << ((meta >> TEC_META_CLASS_SHIFT) & 7u) : 0u;
         bool fresh = hit & (h0 != name);
-        if (FULL) fresh = fresh & (h1 != name) & (h2 != name) & (h3 != name);
+        if (FULL) fresh = fresh & (h1 != name) & (h2 != name) & (h3 != name) & (h4 != name) & (h5 != name);
+        h5 = fresh ? h4 : h5;
+        h4 = fresh ? h3 : h4;
         h3 = fresh ? h2 : h3;
         h2 = fresh ? h1 : h2;
         h1 = fresh ? h0 : h1;
@@ -412,20 +456,36 @@ struct HitSet {
 // Edge tests of one list for a unit that is NOT on a 10 kb boundary (every hit is then a bucket
 // candidate, see is_candidate).  t1_on / t2_on: is p1 / p2 inside this record's bin?  x1 / x2 are
 // the positions relative to (bin start - 1).  Inline slots beyond the bin's count are zero and
-// fail both tests by themselves; entries beyond NE continue in the CSR list (absolute tests).
+// fail both tests by themselves.  Entries NE..NE+3 arrive as two prefetched continuation pieces
+// (c0, c1: zero when the list is shorter); the branches around them are wave-uniform.  Lists
+// longer than NE + 4 (0.1 % of the hg38-like lookups) walk the rest of their continuation run.
+template <bool MIXED, bool FULL>
+__device__ __forceinline__ void test_compact(uint32_t lr, uint32_t meta, int x1, int x2, bool t1_on, bool t2_on, HitSet& hs) {
+    const int l = (int)(lr & 0xFFFFu), g = (int)(lr >> 16);
+    const bool t1 = t1_on & (x1 >= l) & (x1 < g);
+    const bool t2 = t2_on & (x2 > l) & (x2 <= g);
+    hs.add_if<MIXED, FULL>(t1 | t2, meta);
+}
+
 template <int NE, bool MIXED, bool FULL>
-__device__ __forceinline__ void scan_record(const BinRec<NE>& r, const tec_entry* __restrict__ ent, const Unit& u, int x1,
-                                            int x2, bool t1_on, bool t2_on, HitSet& hs) {
+__device__ __forceinline__ void scan_record(const BinRec<NE>& r, const uint4 c0, const uint4 c1,
+                                            const uint4* __restrict__ cont, int x1, int x2, bool t1_on, bool t2_on,
+                                            HitSet& hs) {
 #pragma unroll
-    for (int k = 0; k < NE; ++k) {
-        const int l = (int)(r.lr[k] & 0xFFFFu), g = (int)(r.lr[k] >> 16);
-        const bool t1 = t1_on & (x1 >= l) & (x1 < g);
-        const bool t2 = t2_on & (x2 > l) & (x2 <= g);
-        hs.add_if<MIXED, FULL>(t1 | t2, r.meta[k]);
-    }
-    for (uint32_t k = NE; k < r.n; ++k) {
-        const tec_entry e = ent[r.off + k];
-        hs.add_if<MIXED, FULL>(((int)(t1_on & test1(e, u)) | (int)(t2_on & test2(e, u))) != 0, e.meta);
+    for (int k = 0; k < NE; ++k) test_compact<MIXED, FULL>(r.lr[k], r.meta[k], x1, x2, t1_on, t2_on, hs);
+    if (__builtin_amdgcn_ballot_w64(r.n > (uint32_t)NE) == 0) return;
+    test_compact<MIXED, FULL>(c0.x, c0.y, x1, x2, t1_on, t2_on, hs);
+    test_compact<MIXED, FULL>(c0.z, c0.w, x1, x2, t1_on, t2_on, hs);
+    if (__builtin_amdgcn_ballot_w64(r.n > (uint32_t)NE + 2u) == 0) return;
+    test_compact<MIXED, FULL>(c1.x, c1.y, x1, x2, t1_on, t2_on, hs);
+    test_compact<MIXED, FULL>(c1.z, c1.w, x1, x2, t1_on, t2_on, hs);
+    if (r.n > (uint32_t)NE + 4u) {
+        const uint32_t pieces = (r.n - (uint32_t)NE + 1u) >> 1;
+        for (uint32_t j = 2; j < pieces; ++j) {
+            const uint4 c = cont[r.off + j];
+            test_compact<MIXED, FULL>(c.x, c.y, x1, x2, t1_on, t2_on, hs);
+            test_compact<MIXED, FULL>(c.z, c.w, x1, x2, t1_on, t2_on, hs);
+        }
     }
 }
 
@@ -455,14 +515,10 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     unsigned sinkhole = 0;                // keeps ablated loads alive (TEC_ABLATE diagnostics)
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
-    uint32_t since_flush = 0;
+    TEC_CLK_DECL;
     for (uint64_t s0 = (uint64_t)blockIdx.x * span; s0 < n; s0 += (uint64_t)gridDim.x * span)
     for (uint64_t base = s0; base < n && base < s0 + span; base += chunk) {
-        if (since_flush + chunk > 65535u) {
-            flush_hist(hist, words, counts);
-            since_flush = 0;
-        }
-        since_flush += chunk;
+        TEC_CLK(4);  // loop overhead + flushes
         // ---- stage 1: the unit SoA (streamed, non-temporal)
         unsigned fl[U], mq[U];
         int ch[U];
@@ -484,6 +540,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             for (int k = 0; k < U; ++k) sinkhole ^= fl[k] ^ mq[k] ^ (unsigned)ch[k] ^ (unsigned)un[k].p1 ^ (unsigned)un[k].p2;
             continue;
         }
+        TEC_CLK(0);  // stream latency
         // ---- stage 2: filters, one bin record per edge (a single gather level)
         BinRec<NE> ra[U], rb[U];
         bool one[U];
@@ -530,6 +587,23 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                 if (live[k]) sinkhole ^= ra[k].n ^ rb[k].n ^ ra[k].meta[NE - 1] ^ rb[k].lr[NE - 1];
             continue;
         }
+        TEC_CLK(1);  // record gathers
+        // ---- stage 2b: entries NE..NE+3 of the longer lists, all in flight together (the
+        // continuation table is a few MB: L2 / Infinity Cache hits)
+        uint4 ca0[U], ca1[U], cb0[U], cb1[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            ca0[k] = ca1[k] = cb0[k] = cb1[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (ra[k].n > (uint32_t)NE) {
+                ca0[k] = idx.cont[ra[k].off];
+                if (ra[k].n > (uint32_t)NE + 2u) ca1[k] = idx.cont[ra[k].off + 1u];
+            }
+            if (rb[k].n > (uint32_t)NE) {
+                cb0[k] = idx.cont[rb[k].off];
+                if (rb[k].n > (uint32_t)NE + 2u) cb1[k] = idx.cont[rb[k].off + 1u];
+            }
+        }
+        TEC_CLK(2);  // continuation gathers
         // ---- stage 3: edge tests over the records, distinct names, count
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -539,17 +613,25 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             const unsigned q2 = ((unsigned)u.p2 + 1u) / (unsigned)TEC_BUCKET_SIZE;
             u.boundary = u.p1 < 0 || u.p2 < 0 || u.p2 == 0x7FFFFFFF || (unsigned)u.p1 == q1 * TEC_BUCKET_SIZE ||
                          (unsigned)u.p2 + 1u == q2 * TEC_BUCKET_SIZE;
-            HitSet hs{kNoName, kNoName, kNoName, kNoName, 0u, 0u};
+            HitSet hs{kNoName, kNoName, kNoName, kNoName, kNoName, kNoName, 0u, 0u};
             if (!u.boundary) {
-                scan_record<NE, MIXED, false>(ra[k], ent, u, xa1[k], xa2[k], true, one[k], hs);
-                scan_record<NE, MIXED, true>(rb[k], ent, u, 0, xb2[k], false, true, hs);
+                scan_record<NE, MIXED, false>(ra[k], ca0[k], ca1[k], idx.cont, xa1[k], xa2[k], true, one[k], hs);
+                scan_record<NE, MIXED, true>(rb[k], cb0[k], cb1[k], idx.cont, 0, xb2[k], false, true, hs);
             }
             // exact CSR walk for the rare rest: p1 or p2+1 on a 10 kb boundary (the reference's
-            // bucket-candidate rule can bite there), or more than four distinct names
-            if (u.boundary || hs.n > 4u) {
-                uint32_t a0 = ra[k].off, a1 = ra[k].off + ra[k].n, b0 = rb[k].off, b1 = rb[k].off + rb[k].n;
-                if (ra[k].n == 0) { a0 = b0; a1 = b1; }
-                if (rb[k].n == 0) { b0 = a0; b1 = a1; }
+            // bucket-candidate rule can bite there), or more than six distinct names
+            if (u.boundary || hs.n > kHitSlots) {
+                // (the records carry no CSR offsets: look the lists up again; ch is in range, and a
+                // record with n > 0 means its edge lies inside the chromosome's bins)
+                const uint32_t cbx = chrom_in_lds ? chrom_tab[ch[k]].x : idx.chrom_base[ch[k]];
+                const uint32_t ga = cbx + ((uint32_t)u.p1 >> idx.shift);
+                const uint32_t gb = one[k] ? ga : cbx + ((uint32_t)u.p2 >> idx.shift);
+                uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                if (ra[k].n) { a0 = idx.bin_off[ga]; a1 = idx.bin_off[ga + 1]; }
+                if (one[k]) { b0 = a0; b1 = a1; }
+                else if (rb[k].n) { b0 = idx.bin_off[gb]; b1 = idx.bin_off[gb + 1]; }
+                if (a0 == a1) { a0 = b0; a1 = b1; }
+                if (b0 == b1) { b0 = a0; b1 = a1; }
                 const tec_entry ea = ent[a0], eb = ent[b0];
                 if (MIXED) {
                     const uint32_t classes = walk_hits<false>(ent, u, a0, a1, b0, b1, ea, eb, sink);
@@ -570,17 +652,38 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                 continue;
             }
             if (mute) continue;
-            fast.add(hs.h0);
+            // all adds of the unit first, then one look at the words they replaced
+            uint32_t o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0;
+            const uint32_t o0 = fast.add(hs.h0);
             if (hs.n > 1) {
-                fast.add(hs.h1);
+                o1 = fast.add(hs.h1);
                 if (hs.n > 2) {
-                    fast.add(hs.h2);
-                    if (hs.n > 3) fast.add(hs.h3);
+                    o2 = fast.add(hs.h2);
+                    if (hs.n > 3) {
+                        o3 = fast.add(hs.h3);
+                        if (hs.n > 4) {
+                            o4 = fast.add(hs.h4);
+                            if (hs.n > 5) o5 = fast.add(hs.h5);
+                        }
+                    }
                 }
             }
+            // absent adds left o = 0 and a name whose half of 0 is not 0xFFFF: never a carry
+            if ((uint32_t)wrapped(hs.h0, o0, 1u) | (uint32_t)wrapped(hs.h1, o1, 1u) | (uint32_t)wrapped(hs.h2, o2, 1u) |
+                (uint32_t)wrapped(hs.h3, o3, 1u) | (uint32_t)wrapped(hs.h4, o4, 1u) | (uint32_t)wrapped(hs.h5, o5, 1u)) {
+                if (wrapped(hs.h0, o0, 1u)) wrap_account(counts, hs.h0, o0);
+                if (wrapped(hs.h1, o1, 1u)) wrap_account(counts, hs.h1, o1);
+                if (wrapped(hs.h2, o2, 1u)) wrap_account(counts, hs.h2, o2);
+                if (wrapped(hs.h3, o3, 1u)) wrap_account(counts, hs.h3, o3);
+                if (wrapped(hs.h4, o4, 1u)) wrap_account(counts, hs.h4, o4);
+                if (wrapped(hs.h5, o5, 1u)) wrap_account(counts, hs.h5, o5);
+            }
         }
+        TEC_CLK(3);  // tests + counting
     }
     flush_hist(hist, words, counts);
+    TEC_CLK(5);  // final flush
+    TEC_CLK_STORE;
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     n_assigned = wave_sum(n_assigned);
@@ -756,7 +859,7 @@ extern "C" int tec_bulk_begin(tec_ctx* ctx, int mapq_min) {
     ctx->mapq_min = mapq_min;
     ctx->kernel_ms = 0.0;
     ctx->kernel_launches = 0;
-    TEC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ctx->idx.n_names * sizeof(unsigned long long), ctx->s_compute));
+    TEC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)ctx->idx.n_names + 2) * sizeof(unsigned long long), ctx->s_compute));
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), ctx->s_compute));
     ctx->bulk_open = true;
     return TEC_OK;
@@ -870,6 +973,18 @@ extern "C" int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats)
                         h[5]);
     return TEC_OK;
 }
+
+#ifdef TEC_DIAGNOSTICS
+// diagnostics: read and clear the per-stage cycle sums (stream, records, continuation, tests+count,
+// loop+flushes, final flush) accumulated by wave 0 of every workgroup
+extern "C" int tec_diag_stage_clocks(tec_ctx* ctx, unsigned long long* out) {
+    TEC_HIP(ctx, hipDeviceSynchronize());
+    TEC_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_clk), 8 * sizeof(unsigned long long)));
+    unsigned long long zero[8] = {0};
+    TEC_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_stage_clk), zero, sizeof zero));
+    return TEC_OK;
+}
+#endif
 
 extern "C" int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* launches) {
     if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_kernel_time: NULL context");

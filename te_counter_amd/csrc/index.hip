@@ -9,11 +9,17 @@
 //   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by (name id, strand) inside a fine bin
 //   chrom_base[n_chrom], chrom_nbins[n_chrom]
 //   recs[n_bins]          compact bin records for the bulk kernel: {n = entries in the bin,
-//                         off = bin_off[bin], the bin's first NE entries as {left16 | right16<<16,
-//                         meta}} with coordinates relative to (bin start - 1) and clamped to the
-//                         bin -- 32 bytes for NE = 3.  One record answers an edge lookup for every
-//                         bin with at most NE entries (one dependent gather level instead of two);
-//                         longer lists continue at entries[off + NE].
+//                         coff, the bin's first NE entries as {left16 | right16<<16, meta}} with
+//                         coordinates relative to (bin start - 1) and clamped to the bin -- 32
+//                         bytes for NE = 3.  One record answers an edge lookup for every bin with
+//                         at most NE entries (one dependent gather level instead of two).
+//   cont[]                continuation of the longer lists in the same compact 8-byte form, two
+//                         entries per 16-byte piece, a bin's run starting at piece `coff` (zero
+//                         padded to a whole piece).  Only ~8 % of the hg38-like bins have one, so
+//                         the table is a few MB and stays in L2 / Infinity Cache: a lane fetches
+//                         entries NE..NE+3 of both edges in ONE further round trip, all loads in
+//                         flight together, instead of walking the 16-byte CSR entries one dependent
+//                         HBM gather at a time.
 // A feature [left, right] is filed under every fine bin (2^shift bp) that intersects
 // [left-1, right+1]: any read edge that can pass one of the reference's 2-bp edge tests
 // (te_count.py:122,125 / 237,240 / 645,648) then finds the feature in the ONE fine bin of that
@@ -181,9 +187,23 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const int rec_ne = shift <= 15 ? ctx->rec_ne_wanted : 0;
     const size_t rec_words = rec_ne ? 2 + 2 * (size_t)rec_ne : 0;
     const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
-    const size_t total = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * rec_words * 4 + 16, 256);
     std::vector<uint32_t> recs((size_t)std::max<uint64_t>(n_bins, 1) * rec_words + 4, 0u);
+    std::vector<uint32_t> cont;  // 4 words per piece = two {left16 | right16<<16, meta} entries
     if (rec_ne) {
+        uint64_t pieces = 0;
+        for (uint64_t b = 0; b < n_bins; ++b) {
+            const uint32_t cnt = bin_off[b + 1] - bin_off[b];
+            if (cnt > (uint32_t)rec_ne) pieces += (cnt - rec_ne + 1) / 2;
+        }
+        if (pieces >= 0xFFFFFFF0ull)
+            return tec_fail(ctx, TEC_EOVERFLOW, "tec_index_build: %llu continuation pieces exceed 32-bit offsets",
+                            (unsigned long long)pieces);
+        cont.assign((size_t)(pieces + 2) * 4, 0u);  // two zero pieces at the end: a lane may read one piece too far
+    }
+    const size_t o_cont = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * rec_words * 4 + 16, 256);
+    const size_t total = align_up(o_cont + std::max<size_t>(cont.size(), 8) * 4, 256);
+    if (rec_ne) {
+        uint64_t piece = 0;
         const int64_t width = (int64_t)1 << shift;
         uint64_t b = 0;
         for (uint32_t c = 0; c < n_chrom; ++c)
@@ -192,13 +212,15 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
                 const uint32_t a = bin_off[b], cnt = bin_off[b + 1] - a;
                 const int64_t start = (int64_t)lb << shift;
                 r[0] = cnt;
-                r[1] = a;
-                for (uint32_t k = 0; k < cnt && k < (uint32_t)rec_ne; ++k) {
+                r[1] = cnt > (uint32_t)rec_ne ? (uint32_t)piece : 0u;
+                for (uint32_t k = 0; k < cnt; ++k) {
                     const int64_t l = std::min<int64_t>(std::max<int64_t>((int64_t)entries[a + k].left - start + 1, 0), width + 2);
                     const int64_t g = std::min<int64_t>(std::max<int64_t>((int64_t)entries[a + k].right - start + 1, 0), width + 2);
-                    r[2 + 2 * k] = (uint32_t)l | ((uint32_t)g << 16);
-                    r[3 + 2 * k] = entries[a + k].meta;
+                    uint32_t* w = k < (uint32_t)rec_ne ? &r[2 + 2 * k] : &cont[(size_t)piece * 4 + 2 * (k - rec_ne)];
+                    w[0] = (uint32_t)l | ((uint32_t)g << 16);
+                    w[1] = entries[a + k].meta;
                 }
+                if (cnt > (uint32_t)rec_ne) piece += (cnt - rec_ne + 1) / 2;
             }
     }
     void* blob = nullptr;
@@ -218,12 +240,15 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (e == hipSuccess) e = hipMemcpy(p + o_cb, chrom_base.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cn, chrom_nbins.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_rec, recs.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(p + o_cont, 0, total - o_cont);
+    if (e == hipSuccess && !cont.empty()) e = hipMemcpy(p + o_cont, cont.data(), cont.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     unsigned long long* counts = nullptr;
     uint32_t* d_i2e = nullptr;
     if (e == hipSuccess) e = hipMalloc(&d_i2e, (size_t)n_names * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(d_i2e, int2ext.data(), (size_t)n_names * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&counts, (size_t)n_names * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(counts, 0, (size_t)n_names * sizeof(unsigned long long));
+    // + 2: the carry bookkeeping of the packed LDS counters may touch the slot after the last name (bulk.hip)
+    if (e == hipSuccess) e = hipMalloc(&counts, ((size_t)n_names + 2) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(counts, 0, ((size_t)n_names + 2) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipFree(blob);
         if (counts) (void)hipFree(counts);
@@ -241,6 +266,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     ctx->idx.chrom_base = reinterpret_cast<const uint32_t*>(p + o_cb);
     ctx->idx.chrom_nbins = reinterpret_cast<const uint32_t*>(p + o_cn);
     ctx->idx.recs = reinterpret_cast<const uint4*>(p + o_rec);
+    ctx->idx.cont = reinterpret_cast<const uint4*>(p + o_cont);
+    ctx->cont_bytes = cont.size() * sizeof(uint32_t);
     ctx->rec_ne = rec_ne;
     ctx->idx.n_chrom = n_chrom;
     ctx->idx.n_names = n_names;

@@ -26,7 +26,8 @@ struct tec_index_dev {
     const tec_entry* entries;     // [n_entries], sorted by name id inside each fine bin
     const uint32_t* chrom_base;   // [n_chrom] first fine bin of each chromosome
     const uint32_t* chrom_nbins;  // [n_chrom] number of fine bins of each chromosome
-    const uint4* recs;            // [n_bins] compact bin records {n, off, NE x {left16|right16<<16, meta}}: see index.hip
+    const uint4* recs;            // [n_bins] compact bin records {n, coff, NE x {left16|right16<<16, meta}}: see index.hip
+    const uint4* cont;            // continuation pieces (two compact entries each) of bins with more than NE entries
     uint32_t n_chrom;
     uint32_t n_names;
     int shift;
@@ -57,7 +58,7 @@ struct tec_ctx {
     bool have_index = false;
     tec_index_dev idx{};
     void* d_index_blob = nullptr;
-    uint64_t n_entries = 0, n_bins = 0, index_bytes = 0;
+    uint64_t n_entries = 0, n_bins = 0, index_bytes = 0, cont_bytes = 0;
     std::vector<uint32_t> int2ext;  // internal (hotness-ordered) name id -> caller's name id
     uint32_t* d_int2ext = nullptr;
 
