@@ -153,6 +153,10 @@ int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats);
  * launches since tec_bulk_begin; for bench.py's roofline figure. */
 int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* launches);
 
+/* Duration (ms) of the small kernels that fold the per-workgroup histogram rows into the count
+ * vector after each count kernel, since tec_bulk_begin. */
+int tec_bulk_reduce_time(tec_ctx* ctx, double* total_ms);
+
 
 /* ---- Single-cell counting (--sc --se) ------------------------------------------------------
  * Replaces measureTE.sc_parse_bamse (te_count.py:298-707).  The host decoder hands over, per

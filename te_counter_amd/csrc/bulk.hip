@@ -223,24 +223,37 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
-// Final flush of the per-workgroup histogram (once per launch).  Every wave drains its own outstanding LDS atomics before
-// the barrier (an explicit s_waitcnt: hipcc 7.2 was seen to omit it on one loop path of the U = 2
-// record kernel, and a late ds_add that lands between another lane's read and clear of the same
-// word is a lost update -- caught by tools/stress_determinism.py as 30 missing counts in ~2 % of
-// launches), and the read-and-clear is one atomic exchange, so even a stray add can only be
-// deferred to the next flush, never lost.
-__device__ __forceinline__ void flush_hist(uint32_t* hist, uint32_t words, unsigned long long* counts) {
+// End of a launch: the workgroup's histogram goes to its own row of the slab with plain 16-byte
+// stores, and reduce_slabs_kernel sums the rows into the 64-bit count vector.  (256 workgroups
+// flushing 41 k counters each with global atomics -- 10 M memory-side atomics on the same 41 k
+// addresses -- took ~20 % of the launch.)  Every wave drains its own outstanding LDS atomics
+// before the barrier with an explicit s_waitcnt: hipcc 7.2 was seen to omit it on one loop path of
+// the U = 2 record kernel, and a ds_add still in flight when another lane reads the word is a
+// lost update (caught by tools/stress_determinism.py as 30 missing counts in ~2 % of launches).
+__device__ __forceinline__ void store_hist(const uint32_t* hist, uint32_t words4, uint32_t* slab_row) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    for (uint32_t w = threadIdx.x; w < words; w += kBlock) {
-        const uint32_t v = atomicExch(&hist[w], 0u);
-        if (v) {
-            if (v & 0xFFFFu) atomicAdd(&counts[2 * w], (unsigned long long)(v & 0xFFFFu));
-            if (v >> 16) atomicAdd(&counts[2 * w + 1], (unsigned long long)(v >> 16));
-        }
+    const uint4* src = reinterpret_cast<const uint4*>(hist);
+    uint4* dst = reinterpret_cast<uint4*>(slab_row);
+    for (uint32_t q = threadIdx.x; q < words4 / 4u; q += kBlock) dst[q] = src[q];
+}
+
+// counts[2w] += sum over rows of the low halves of word w, counts[2w+1] += the high halves.
+// blockIdx.y strides over the rows so that enough loads are in flight.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const uint32_t* __restrict__ slabs, uint32_t stride,
+                                                           uint32_t words, uint32_t rows,
+                                                           unsigned long long* counts) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= words) return;
+    uint32_t lo = 0, hi = 0;  // <= 65 535 per row, a few hundred rows
+#pragma unroll 8
+    for (uint32_t g = blockIdx.y; g < rows; g += gridDim.y) {
+        const uint32_t v = slabs[(size_t)g * stride + w];
+        lo += v & 0xFFFFu;
+        hi += v >> 16;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (lo) atomicAdd(&counts[2u * w], (unsigned long long)lo);
+    if (hi) atomicAdd(&counts[2u * w + 1u], (unsigned long long)hi);
 }
 
 // MIXED = the index holds classes that are not countable in bulk (miRNA..., enhancer): the class
@@ -259,10 +272,11 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
                                                            const uint16_t* __restrict__ flag,
                                                            const uint8_t* __restrict__ mapq, uint64_t n, int mapq_min,
                                                            unsigned long long* counts, unsigned long long* stats,
-                                                           uint32_t k_lds, uint64_t span, uint32_t flags) {
+                                                           uint32_t k_lds, uint64_t span, uint32_t flags,
+                                                           uint32_t* slabs) {
     extern __shared__ uint32_t hist[];
     constexpr uint32_t chunk = U * kBlock;
-    const uint32_t words = (k_lds + 1u) >> 1;
+    const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // whole 16-byte pieces
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
             }
         }
     }
-    flush_hist(hist, words, counts);
+    store_hist(hist, words, slabs + (size_t)blockIdx.x * words);
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     n_assigned = wave_sum(n_assigned);
@@ -497,15 +511,16 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                                                                const uint8_t* __restrict__ mapq, uint64_t n,
                                                                int mapq_min, unsigned long long* counts,
                                                                unsigned long long* stats, uint32_t k_lds, uint64_t span,
-                                                               uint32_t flags) {
+                                                               uint32_t flags, uint32_t* slabs) {
     extern __shared__ uint32_t hist[];
     // per-chromosome {first fine bin, bin count} in LDS: one dependent global gather less per unit
     __shared__ uint2 chrom_tab[kChromLds];
+    __shared__ uint32_t ticket;
+    if (threadIdx.x == 0) ticket = 0;
     const bool chrom_in_lds = idx.n_chrom <= kChromLds;
     if (chrom_in_lds)
         for (uint32_t c = threadIdx.x; c < idx.n_chrom; c += kBlock) chrom_tab[c] = make_uint2(idx.chrom_base[c], idx.chrom_nbins[c]);
-    constexpr uint32_t chunk = U * kBlock;
-    const uint32_t words = (k_lds + 1u) >> 1;
+    const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // whole 16-byte pieces
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -516,9 +531,26 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     const tec_entry* __restrict__ ent = idx.entries;
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     TEC_CLK_DECL;
-    for (uint64_t s0 = (uint64_t)blockIdx.x * span; s0 < n; s0 += (uint64_t)gridDim.x * span)
-    for (uint64_t base = s0; base < n && base < s0 + span; base += chunk) {
-        TEC_CLK(4);  // loop overhead + flushes
+    // A workgroup owns spans of consecutive units, `gridDim.x` spans apart (see count_bulk_kernel).
+    // Inside the workgroup the waves DRAW their pieces of U x 64 consecutive units from a ticket
+    // counter in LDS instead of owning a fixed slice of every chunk: with fixed slices the
+    // first-launched (oldest, issue-favoured) waves finished ~18 % ahead and then idled at the
+    // final barrier while the rest ran on with too few waves left to hide the gather latency.
+    constexpr uint32_t piece = U * 64u;
+    const uint32_t per_span = (uint32_t)(span / piece);  // span is a whole number of chunks
+    const uint64_t n_spans = (n + span - 1) / span;
+    const uint64_t my_spans = blockIdx.x < n_spans ? (n_spans - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t tickets = (uint32_t)(my_spans * per_span);  // the host keeps this below 2^32
+    const unsigned lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&ticket, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= tickets) break;
+        const uint32_t sj = t / per_span, sr = t - sj * per_span;
+        const uint64_t base = ((uint64_t)blockIdx.x + (uint64_t)sj * gridDim.x) * span + (uint64_t)sr * piece;
+        if (base >= n) continue;  // the tail of the batch's last span
+        TEC_CLK(4);  // loop overhead
         // ---- stage 1: the unit SoA (streamed, non-temporal)
         unsigned fl[U], mq[U];
         int ch[U];
@@ -526,7 +558,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
         bool live[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+            const uint64_t i = base + (uint64_t)k * 64u + lane;
             live[k] = i < n;
             const uint64_t ii = live[k] ? i : 0;
             fl[k] = __builtin_nontemporal_load(&flag[ii]);
@@ -681,7 +713,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
         }
         TEC_CLK(3);  // tests + counting
     }
-    flush_hist(hist, words, counts);
+    store_hist(hist, words, slabs + (size_t)blockIdx.x * words);
     TEC_CLK(5);  // final flush
     TEC_CLK_STORE;
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
@@ -702,7 +734,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
 
 typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
                                const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t,
-                               uint64_t, uint32_t);
+                               uint64_t, uint32_t, uint32_t*);
 
 template <int U>
 count_kernel_t pick_rec(bool mixed, bool all_lds) {
@@ -752,6 +784,8 @@ int harvest_timers(tec_ctx* ctx) {
         float ms = 0.f;
         TEC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].start, ctx->ev_pool[i].stop));
         ctx->kernel_ms += ms;
+        TEC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].stop, ctx->ev_pool[i].reduced));
+        ctx->reduce_ms += ms;
     }
     ctx->ev_used = 0;
     return TEC_OK;
@@ -768,6 +802,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
             tec_event_pair p;
             TEC_HIP(ctx, hipEventCreate(&p.start));
             TEC_HIP(ctx, hipEventCreate(&p.stop));
+            TEC_HIP(ctx, hipEventCreate(&p.reduced));
             ctx->ev_pool.push_back(p);
         }
     }
@@ -781,18 +816,36 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     uint32_t budget = ctx->lds_bytes;
     if (budget == 0) budget = (size_t)ctx->idx.n_names * 2 <= kLdsBytes ? kLdsBytes : kLdsMaxBytes;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, budget / 2);
-    const size_t lds = (size_t)((k_lds + 1) / 2) * 4;
+    const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // as the kernels compute it
+    const size_t lds = (size_t)words * 4;
     const unsigned wg_per_cu = lds <= kLdsBytes ? 2u : 1u;
     const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * wg_per_cu);
+    // one histogram row per workgroup; reduce_slabs_kernel folds them into the count vector
+    const size_t slab_bytes = (size_t)grid * words * sizeof(uint32_t);
+    if (slab_bytes > ctx->slab_cap) {
+        TEC_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
+        if (ctx->d_slabs) TEC_HIP(ctx, hipFree(ctx->d_slabs));
+        ctx->d_slabs = nullptr;
+        ctx->slab_cap = 0;
+        TEC_HIP(ctx, hipMalloc(&ctx->d_slabs, slab_bytes));
+        ctx->slab_cap = slab_bytes;
+    }
     // spans: ~span_div per workgroup, each a whole number of chunks
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
     hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
                        u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                       (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate);
+                       (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, ctx->d_slabs);
     TEC_HIP(ctx, hipGetLastError());
     TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
+    {
+        const unsigned split = std::max(1u, std::min(grid / 16u, 32u));  // >= 16 rows per thread
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((words + 255u) / 256u, split), dim3(256), 0, ctx->s_compute,
+                           ctx->d_slabs, words, words, grid, ctx->d_counts);
+        TEC_HIP(ctx, hipGetLastError());
+    }
+    TEC_HIP(ctx, hipEventRecord(ev.reduced, ctx->s_compute));
     ++ctx->kernel_launches;
     return TEC_OK;
 }
@@ -806,7 +859,7 @@ int tec_bulk_init(tec_ctx* ctx) {
             for (int rec : {0, 3})
                 for (int all = 0; all < 2; ++all)
                     TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec, all != 0)),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)(kChromLds * sizeof(uint2))));
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)(kChromLds * sizeof(uint2)) - 64));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
@@ -842,9 +895,13 @@ int tec_bulk_release(tec_ctx* ctx) {
     for (auto& p : ctx->ev_pool) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
+        (void)hipEventDestroy(p.reduced);
     }
     ctx->ev_pool.clear();
     ctx->ev_used = 0;
+    if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
+    ctx->d_slabs = nullptr;
+    ctx->slab_cap = 0;
     return TEC_OK;
 }
 
@@ -858,6 +915,7 @@ extern "C" int tec_bulk_begin(tec_ctx* ctx, int mapq_min) {
     if (rc) return rc;
     ctx->mapq_min = mapq_min;
     ctx->kernel_ms = 0.0;
+    ctx->reduce_ms = 0.0;
     ctx->kernel_launches = 0;
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)ctx->idx.n_names + 2) * sizeof(unsigned long long), ctx->s_compute));
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), ctx->s_compute));
@@ -992,5 +1050,13 @@ extern "C" int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* la
     if (rc) return rc;
     if (total_ms) *total_ms = ctx->kernel_ms;
     if (launches) *launches = ctx->kernel_launches;
+    return TEC_OK;
+}
+
+extern "C" int tec_bulk_reduce_time(tec_ctx* ctx, double* total_ms) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_reduce_time: NULL context");
+    int rc = tec_bulk_sync(ctx);
+    if (rc) return rc;
+    if (total_ms) *total_ms = ctx->reduce_ms;
     return TEC_OK;
 }

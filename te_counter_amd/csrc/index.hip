@@ -246,9 +246,9 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     uint32_t* d_i2e = nullptr;
     if (e == hipSuccess) e = hipMalloc(&d_i2e, (size_t)n_names * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(d_i2e, int2ext.data(), (size_t)n_names * sizeof(uint32_t), hipMemcpyHostToDevice);
-    // + 2: the carry bookkeeping of the packed LDS counters may touch the slot after the last name (bulk.hip)
-    if (e == hipSuccess) e = hipMalloc(&counts, ((size_t)n_names + 2) * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(counts, 0, ((size_t)n_names + 2) * sizeof(unsigned long long));
+    // + 8: the carry bookkeeping of the packed LDS counters may touch the slot after the last name (bulk.hip)
+    if (e == hipSuccess) e = hipMalloc(&counts, ((size_t)n_names + 8) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(counts, 0, ((size_t)n_names + 8) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipFree(blob);
         if (counts) (void)hipFree(counts);

@@ -35,7 +35,7 @@ struct tec_index_dev {
 };
 
 struct tec_event_pair {
-    hipEvent_t start, stop;
+    hipEvent_t start, stop, reduced;  // count kernel between start and stop, slab reduce up to `reduced`
 };
 
 struct tec_slot {  // one staged batch in HBM
@@ -75,7 +75,9 @@ struct tec_ctx {
     uint64_t next_ticket = 1;
     std::vector<tec_event_pair> ev_pool;
     size_t ev_used = 0;
-    double kernel_ms = 0.0;
+    double kernel_ms = 0.0, reduce_ms = 0.0;
+    uint32_t* d_slabs = nullptr;  // [workgroups x histogram words] per-workgroup histogram rows of a launch
+    size_t slab_cap = 0;
     uint64_t kernel_launches = 0;
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel

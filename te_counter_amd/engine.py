@@ -103,6 +103,11 @@ class Engine:
         self._check(self._lib.tec_bulk_kernel_time(self._ctx, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
 
+    def bulk_reduce_time(self):
+        ms = C.c_double()
+        self._check(self._lib.tec_bulk_reduce_time(self._ctx, C.byref(ms)))
+        return ms.value
+
     # ------------------------------------------------------------------ single cell
     def sc_begin(self, stranded, mapq_min, whitelist24, bundle_keys, class_index_chrom, class_skip):
         wl = np.ascontiguousarray(whitelist24, np.uint8)
