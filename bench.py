@@ -119,6 +119,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = eng.bulk_kernel_time()
+    reduce_ms = eng.bulk_reduce_time()
 
     # size-independent property at full size: K passes over one batch = K x one pass
     single, sstats = job(1)
@@ -148,9 +149,13 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic_for(args, n_units),
                          'kernel': 'count_bulk_rec_kernel', 'avg_launch_ms': round(avg_ms, 4),
-                         'algorithmic_bytes_per_launch': alg_bytes},
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'reduce_slabs_kernel_avg_ms': round(reduce_ms / max(1, launches), 4)},
             'assigned_frac': round(sstats['assigned'] / max(1, n_units), 4),
         }
+        tr = out['roofline']['traffic']
+        if tr:  # the rate at which the measured L2<->fabric bytes move: what actually bounds the shuffled case
+            out['roofline']['traffic_GBps'] = round(tr / (avg_ms * 1e-3) / 1e9, 1)
         if args.host_stream and world == 1:
             out['pcie_inclusive'] = host_stream(eng, units, n_units, rec_per_unit)
         if args.cpu_sample and world == 1:
