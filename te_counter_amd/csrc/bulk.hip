@@ -700,9 +700,9 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                     }
                 }
             }
-            // absent adds left o = 0 and a name whose half of 0 is not 0xFFFF: never a carry
-            if ((uint32_t)wrapped(hs.h0, o0, 1u) | (uint32_t)wrapped(hs.h1, o1, 1u) | (uint32_t)wrapped(hs.h2, o2, 1u) |
-                (uint32_t)wrapped(hs.h3, o3, 1u) | (uint32_t)wrapped(hs.h4, o4, 1u) | (uint32_t)wrapped(hs.h5, o5, 1u)) {
+            // absent adds left o = 0: never a carry.  A half that is about to carry (0xFFFF) has its
+            // top bit set: one cheap test over all six words, the exact ones only behind it.
+            if ((o0 | o1 | o2 | o3 | o4 | o5) & 0x80008000u) {
                 if (wrapped(hs.h0, o0, 1u)) wrap_account(counts, hs.h0, o0);
                 if (wrapped(hs.h1, o1, 1u)) wrap_account(counts, hs.h1, o1);
                 if (wrapped(hs.h2, o2, 1u)) wrap_account(counts, hs.h2, o2);
