@@ -28,9 +28,9 @@ constexpr int kBlock = 1024;
 #ifndef TEC_REC_WAVES
 #define TEC_REC_WAVES 4  // min waves per SIMD the record kernel is compiled for (8: two workgroups per CU)
 #endif
-constexpr uint32_t kLdsBytes = 78 * 1024;      // per workgroup: two workgroups fit a CU's 160 KiB
-constexpr uint32_t kLdsMaxBytes = 156 * 1024;  // one workgroup per CU (room for the static chromosome table)
-constexpr uint32_t kChromLds = 256;            // chromosomes whose {base, bins} live in LDS
+constexpr uint32_t kLdsBytes = 75 * 1024;      // per workgroup: two workgroups (+ their static LDS) fit a CU's 160 KiB
+constexpr uint32_t kLdsMaxBytes = 154 * 1024;  // one workgroup per CU (room for the static chromosome table)
+constexpr uint32_t kChromLds = 512;            // the record kernel keeps every chromosome's {base, bins} in LDS
 
 // Diagnostic builds (make EXTRA=-DTEC_DIAGNOSTICS): wave 0 of every workgroup accumulates the
 // shader-clock cycles it spends per stage of the record kernel (with a full s_waitcnt at every
@@ -517,9 +517,8 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     __shared__ uint2 chrom_tab[kChromLds];
     __shared__ uint32_t ticket;
     if (threadIdx.x == 0) ticket = 0;
-    const bool chrom_in_lds = idx.n_chrom <= kChromLds;
-    if (chrom_in_lds)
-        for (uint32_t c = threadIdx.x; c < idx.n_chrom; c += kBlock) chrom_tab[c] = make_uint2(idx.chrom_base[c], idx.chrom_nbins[c]);
+    for (uint32_t c = threadIdx.x; c < kChromLds; c += kBlock)
+        chrom_tab[c] = c < idx.n_chrom ? make_uint2(idx.chrom_base[c], idx.chrom_nbins[c]) : make_uint2(0u, 0u);
     const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // whole 16-byte pieces
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -573,45 +572,38 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             continue;
         }
         TEC_CLK(0);  // stream latency
-        // ---- stage 2: filters, one bin record per edge (a single gather level)
+        // ---- stage 2: filters, one bin record per edge (a single gather level).  Branch-free on
+        // purpose: every lane loads -- a filtered unit or an edge outside the chromosome reads the
+        // all-zero record behind the table -- so that the records of all U units go out back to
+        // back.  (With `if (valid) load` hipcc sank the unpacking into the branches and waited
+        // for each record before issuing the next: four serialized HBM round trips per trip.)
         BinRec<NE> ra[U], rb[U];
         bool one[U];
         int xa1[U], xa2[U], xb2[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            ra[k] = BinRec<NE>{};  // zero entries fail both edge tests
-            rb[k] = BinRec<NE>{};
-            one[k] = false;
-            xa1[k] = xa2[k] = xb2[k] = 0;
-            if (!live[k]) continue;
-            if (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
-                ++n_qc;
-                live[k] = false;
-            } else if ((int)mq[k] < mapq_min) {
-                ++n_lowq;
-                live[k] = false;
-            } else if (ch[k] < 0 || (uint32_t)ch[k] >= idx.n_chrom) {
-                ++n_bad;
-                live[k] = false;
-            } else {
-                uint32_t nb, cb;
-                if (chrom_in_lds) {
-                    const uint2 t = chrom_tab[ch[k]];
-                    cb = t.x;
-                    nb = t.y;
-                } else {
-                    nb = idx.chrom_nbins[ch[k]];
-                    cb = idx.chrom_base[ch[k]];
-                }
-                const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
-                const bool va = un[k].p1 >= 0 && ba < nb, vb = un[k].p2 >= 0 && bb < nb;
-                one[k] = va && vb && ba == bb;  // both edges in one bin: its record answers both tests
-                if (va) ra[k] = load_rec<NE>(idx.recs, cb + ba);
-                if (vb && !one[k]) rb[k] = load_rec<NE>(idx.recs, cb + bb);
-                xa1[k] = un[k].p1 - (int)(ba << idx.shift) + 1;
-                xa2[k] = un[k].p2 - (int)(ba << idx.shift) + 1;
-                xb2[k] = un[k].p2 - (int)(bb << idx.shift) + 1;
-            }
+            const bool qc = live[k] && (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) != 0;
+            const bool lowq = live[k] && !qc && (int)mq[k] < mapq_min;
+            const bool chrom_ok = (uint32_t)ch[k] < idx.n_chrom;  // negative ids wrap to huge values
+            const bool bad = live[k] && !qc && !lowq && !chrom_ok;
+            n_qc += qc ? 1u : 0u;
+            n_lowq += lowq ? 1u : 0u;
+            n_bad += bad ? 1u : 0u;
+            live[k] = live[k] && !qc && !lowq && chrom_ok;
+            const uint32_t chk = chrom_ok ? (uint32_t)ch[k] : 0u;
+            // {first bin, bin count} of the chromosome from LDS (indexes with more than kChromLds
+            // chromosomes run the CSR kernel: a global or FLAT lookup here would make the compiler
+            // drain the outstanding record gathers of the other unit before this one's address)
+            const uint2 t = chrom_tab[chk];
+            const uint32_t cb = t.x, nb = t.y;
+            const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
+            const bool va = live[k] && un[k].p1 >= 0 && ba < nb, vb = live[k] && un[k].p2 >= 0 && bb < nb;
+            one[k] = va && vb && ba == bb;  // both edges in one bin: its record answers both tests
+            ra[k] = load_rec<NE>(idx.recs, va ? cb + ba : idx.zero_rec);
+            rb[k] = load_rec<NE>(idx.recs, vb && !one[k] ? cb + bb : idx.zero_rec);
+            xa1[k] = un[k].p1 - (int)(ba << idx.shift) + 1;
+            xa2[k] = un[k].p2 - (int)(ba << idx.shift) + 1;
+            xb2[k] = un[k].p2 - (int)(bb << idx.shift) + 1;
         }
         if (flags & 4u) {
 #pragma unroll
@@ -624,16 +616,11 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
         // continuation table is a few MB: L2 / Infinity Cache hits)
         uint4 ca0[U], ca1[U], cb0[U], cb1[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            ca0[k] = ca1[k] = cb0[k] = cb1[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (ra[k].n > (uint32_t)NE) {
-                ca0[k] = idx.cont[ra[k].off];
-                if (ra[k].n > (uint32_t)NE + 2u) ca1[k] = idx.cont[ra[k].off + 1u];
-            }
-            if (rb[k].n > (uint32_t)NE) {
-                cb0[k] = idx.cont[rb[k].off];
-                if (rb[k].n > (uint32_t)NE + 2u) cb1[k] = idx.cont[rb[k].off + 1u];
-            }
+        for (int k = 0; k < U; ++k) {  // branch-free as above: shorter lists read the table's zero piece
+            ca0[k] = idx.cont[ra[k].n > (uint32_t)NE ? ra[k].off : idx.zero_piece];
+            ca1[k] = idx.cont[ra[k].n > (uint32_t)NE + 2u ? ra[k].off + 1u : idx.zero_piece];
+            cb0[k] = idx.cont[rb[k].n > (uint32_t)NE ? rb[k].off : idx.zero_piece];
+            cb1[k] = idx.cont[rb[k].n > (uint32_t)NE + 2u ? rb[k].off + 1u : idx.zero_piece];
         }
         TEC_CLK(2);  // continuation gathers
         // ---- stage 3: edge tests over the records, distinct names, count
@@ -655,7 +642,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             if (u.boundary || hs.n > kHitSlots) {
                 // (the records carry no CSR offsets: look the lists up again; ch is in range, and a
                 // record with n > 0 means its edge lies inside the chromosome's bins)
-                const uint32_t cbx = chrom_in_lds ? chrom_tab[ch[k]].x : idx.chrom_base[ch[k]];
+                const uint32_t cbx = idx.chrom_base[ch[k]];
                 const uint32_t ga = cbx + ((uint32_t)u.p1 >> idx.shift);
                 const uint32_t gb = one[k] ? ga : cbx + ((uint32_t)u.p2 >> idx.shift);
                 uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
@@ -811,8 +798,8 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const uint64_t chunk = (uint64_t)unroll * kBlock;
     const uint64_t want = (n + chunk - 1) / chunk;
     const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0 || ctx->force_mixed;
-    // LDS histogram: every name if that fits (two workgroups per CU up to 79 KiB each, else one
-    // workgroup with up to 158 KiB); beyond that the coldest names spill to global atomics.
+    // LDS histogram: every name if that fits (two workgroups per CU up to 75 KiB each, else one
+    // workgroup with up to 154 KiB); beyond that the coldest names spill to global atomics.
     uint32_t budget = ctx->lds_bytes;
     if (budget == 0) budget = (size_t)ctx->idx.n_names * 2 <= kLdsBytes ? kLdsBytes : kLdsMaxBytes;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, budget / 2);
@@ -834,7 +821,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
-    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
+    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 && ctx->idx.n_chrom <= kChromLds ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
                        u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
                        (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, ctx->d_slabs);
     TEC_HIP(ctx, hipGetLastError());
@@ -853,7 +840,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
 }  // namespace
 
 int tec_bulk_init(tec_ctx* ctx) {
-    // 79 KiB of dynamic LDS per workgroup needs the opt-in above the 64 KiB default
+    // more than 64 KiB of dynamic LDS per workgroup needs the opt-in
     for (int mixed = 0; mixed < 2; ++mixed)
         for (int u : {1, 2, 4})
             for (int rec : {0, 3})
@@ -879,7 +866,7 @@ int tec_bulk_init(tec_ctx* ctx) {
     ctx->ablate = 0;
 #endif
     e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup
-    ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 156 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
+    ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 154 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
     e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
     ctx->span_div = e && atoi(e) > 0 ? atoi(e) : 8;
     return TEC_OK;

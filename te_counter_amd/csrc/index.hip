@@ -187,7 +187,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const int rec_ne = shift <= 15 ? ctx->rec_ne_wanted : 0;
     const size_t rec_words = rec_ne ? 2 + 2 * (size_t)rec_ne : 0;
     const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
-    std::vector<uint32_t> recs((size_t)std::max<uint64_t>(n_bins, 1) * rec_words + 4, 0u);
+    std::vector<uint32_t> recs((size_t)(n_bins + 1) * rec_words + 4, 0u);  // + one all-zero record (idx.zero_rec)
+    uint64_t n_pieces = 0;
     std::vector<uint32_t> cont;  // 4 words per piece = two {left16 | right16<<16, meta} entries
     if (rec_ne) {
         uint64_t pieces = 0;
@@ -198,9 +199,10 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
         if (pieces >= 0xFFFFFFF0ull)
             return tec_fail(ctx, TEC_EOVERFLOW, "tec_index_build: %llu continuation pieces exceed 32-bit offsets",
                             (unsigned long long)pieces);
-        cont.assign((size_t)(pieces + 2) * 4, 0u);  // two zero pieces at the end: a lane may read one piece too far
+        cont.assign((size_t)(pieces + 2) * 4, 0u);  // two zero pieces at the end (idx.zero_piece; a lane may read one piece too far)
+        n_pieces = pieces;
     }
-    const size_t o_cont = align_up(o_rec + std::max<uint64_t>(n_bins, 1) * rec_words * 4 + 16, 256);
+    const size_t o_cont = align_up(o_rec + (n_bins + 1) * rec_words * 4 + 16, 256);
     const size_t total = align_up(o_cont + std::max<size_t>(cont.size(), 8) * 4, 256);
     if (rec_ne) {
         uint64_t piece = 0;
@@ -268,6 +270,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     ctx->idx.recs = reinterpret_cast<const uint4*>(p + o_rec);
     ctx->idx.cont = reinterpret_cast<const uint4*>(p + o_cont);
     ctx->cont_bytes = cont.size() * sizeof(uint32_t);
+    ctx->idx.zero_rec = (uint32_t)n_bins;
+    ctx->idx.zero_piece = (uint32_t)n_pieces;
     ctx->rec_ne = rec_ne;
     ctx->idx.n_chrom = n_chrom;
     ctx->idx.n_names = n_names;

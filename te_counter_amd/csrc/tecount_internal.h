@@ -28,6 +28,8 @@ struct tec_index_dev {
     const uint32_t* chrom_nbins;  // [n_chrom] number of fine bins of each chromosome
     const uint4* recs;            // [n_bins] compact bin records {n, coff, NE x {left16|right16<<16, meta}}: see index.hip
     const uint4* cont;            // continuation pieces (two compact entries each) of bins with more than NE entries
+    uint32_t zero_rec;            // index of an all-zero record behind the table (n_bins)
+    uint32_t zero_piece;          // index of an all-zero continuation piece behind the table
     uint32_t n_chrom;
     uint32_t n_names;
     int shift;
