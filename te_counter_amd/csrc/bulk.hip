@@ -417,10 +417,12 @@ struct BinRec {
     uint32_t lr[NE], meta[NE];
 };
 
+// The table is below 4 GiB (index.hip refuses to build records otherwise), so the address is the
+// scalar base plus a 32-bit byte offset: no 64-bit vector address arithmetic.
 template <int NE>
 __device__ __forceinline__ BinRec<NE> load_rec(const uint4* __restrict__ recs, uint32_t g) {
     constexpr int Q = (NE + 1) / 2;  // 16-byte pieces per record
-    const uint4* p = recs + (size_t)Q * g;
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + (uint32_t)(g * (uint32_t)(Q * 16)));
     uint4 q[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) q[i] = p[i];
@@ -467,6 +469,11 @@ struct HitSet {
     }
 };
 
+// continuation piece i (the table is below 4 GiB as well: 32-bit byte offset)
+__device__ __forceinline__ uint4 load_piece(const uint4* __restrict__ cont, uint32_t i) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(cont) + (uint32_t)(i << 4));
+}
+
 // Edge tests of one list for a unit that is NOT on a 10 kb boundary (every hit is then a bucket
 // candidate, see is_candidate).  t1_on / t2_on: is p1 / p2 inside this record's bin?  x1 / x2 are
 // the positions relative to (bin start - 1).  Inline slots beyond the bin's count are zero and
@@ -496,7 +503,7 @@ __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const uint4 c0,
     if (r.n > (uint32_t)NE + 4u) {
         const uint32_t pieces = (r.n - (uint32_t)NE + 1u) >> 1;
         for (uint32_t j = 2; j < pieces; ++j) {
-            const uint4 c = cont[r.off + j];
+            const uint4 c = load_piece(cont, r.off + j);
             test_compact<MIXED, FULL>(c.x, c.y, x1, x2, t1_on, t2_on, hs);
             test_compact<MIXED, FULL>(c.z, c.w, x1, x2, t1_on, t2_on, hs);
         }
@@ -525,10 +532,13 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     __syncthreads();
     const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};  // exact path only
     const FastSink<ALL_LDS> fast{hist, k_lds, counts};
-    const bool mute = (flags & 2u) != 0;  // TEC_ABLATE diagnostics
-    unsigned sinkhole = 0;                // keeps ablated loads alive (TEC_ABLATE diagnostics)
+#ifdef TEC_DIAGNOSTICS
+    const bool mute = (flags & 2u) != 0;  // TEC_ABLATE
+    unsigned sinkhole = 0;                // keeps ablated loads alive
+#endif
     const tec_entry* __restrict__ ent = idx.entries;
-    unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
+    unsigned n_assigned = 0, n_enh = 0;        // per lane (incremented in divergent code)
+    unsigned w_lowq = 0, w_bad = 0, w_qc = 0;  // per wave (scalar)
     TEC_CLK_DECL;
     // A workgroup owns spans of consecutive units, `gridDim.x` spans apart (see count_bulk_kernel).
     // Inside the workgroup the waves DRAW their pieces of U x 64 consecutive units from a ticket
@@ -550,27 +560,40 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
         const uint64_t base = ((uint64_t)blockIdx.x + (uint64_t)sj * gridDim.x) * span + (uint64_t)sr * piece;
         if (base >= n) continue;  // the tail of the batch's last span
         TEC_CLK(4);  // loop overhead
-        // ---- stage 1: the unit SoA (streamed, non-temporal)
+        // ---- stage 1: the unit SoA (streamed, non-temporal).  `base` is wave-uniform, so every
+        // address is a scalar base plus a 32-bit lane offset (no 64-bit vector address math)
         unsigned fl[U], mq[U];
         int ch[U];
         Unit un[U];
         bool live[U];
+        const uint64_t left_u = n - base;
+        const uint32_t left = left_u > (uint64_t)piece ? piece : (uint32_t)left_u;  // units of this piece inside the batch
+        const uint16_t* __restrict__ flag_b = flag + base;
+        const uint8_t* __restrict__ mapq_b = mapq + base;
+        const int32_t* __restrict__ chrom_b = chrom + base;
+        const int32_t* __restrict__ p1_b = p1 + base;
+        const int32_t* __restrict__ p2_b = p2 + base;
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint64_t i = base + (uint64_t)k * 64u + lane;
-            live[k] = i < n;
-            const uint64_t ii = live[k] ? i : 0;
-            fl[k] = __builtin_nontemporal_load(&flag[ii]);
-            mq[k] = __builtin_nontemporal_load(&mapq[ii]);
-            ch[k] = __builtin_nontemporal_load(&chrom[ii]);
-            un[k].p1 = __builtin_nontemporal_load(&p1[ii]);
-            un[k].p2 = __builtin_nontemporal_load(&p2[ii]);
+            const uint32_t i = (uint32_t)k * 64u + lane;
+            live[k] = i < left;
+            const uint32_t ii = live[k] ? i : 0u;
+            fl[k] = __builtin_nontemporal_load(&flag_b[ii]);
+            mq[k] = __builtin_nontemporal_load(&mapq_b[ii]);
+            ch[k] = __builtin_nontemporal_load(&chrom_b[ii]);
+            un[k].p1 = __builtin_nontemporal_load(&p1_b[ii]);
+            un[k].p2 = __builtin_nontemporal_load(&p2_b[ii]);
         }
+        // stage boundaries are scheduling barriers: hipcc otherwise sinks one unit's loads behind
+        // the other unit's waits and the U units run one after the other
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef TEC_DIAGNOSTICS
         if (flags & 8u) {
 #pragma unroll
             for (int k = 0; k < U; ++k) sinkhole ^= fl[k] ^ mq[k] ^ (unsigned)ch[k] ^ (unsigned)un[k].p1 ^ (unsigned)un[k].p2;
             continue;
         }
+#endif
         TEC_CLK(0);  // stream latency
         // ---- stage 2: filters, one bin record per edge (a single gather level).  Branch-free on
         // purpose: every lane loads -- a filtered unit or an edge outside the chromosome reads the
@@ -586,9 +609,10 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             const bool lowq = live[k] && !qc && (int)mq[k] < mapq_min;
             const bool chrom_ok = (uint32_t)ch[k] < idx.n_chrom;  // negative ids wrap to huge values
             const bool bad = live[k] && !qc && !lowq && !chrom_ok;
-            n_qc += qc ? 1u : 0u;
-            n_lowq += lowq ? 1u : 0u;
-            n_bad += bad ? 1u : 0u;
+            // wave-uniform tallies on the scalar unit (one s_bcnt1 each), lane 0 carries them out
+            w_qc += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(qc));
+            w_lowq += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lowq));
+            w_bad += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(bad));
             live[k] = live[k] && !qc && !lowq && chrom_ok;
             const uint32_t chk = chrom_ok ? (uint32_t)ch[k] : 0u;
             // {first bin, bin count} of the chromosome from LDS (indexes with more than kChromLds
@@ -605,23 +629,27 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             xa2[k] = un[k].p2 - (int)(ba << idx.shift) + 1;
             xb2[k] = un[k].p2 - (int)(bb << idx.shift) + 1;
         }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef TEC_DIAGNOSTICS
         if (flags & 4u) {
 #pragma unroll
             for (int k = 0; k < U; ++k)
                 if (live[k]) sinkhole ^= ra[k].n ^ rb[k].n ^ ra[k].meta[NE - 1] ^ rb[k].lr[NE - 1];
             continue;
         }
+#endif
         TEC_CLK(1);  // record gathers
         // ---- stage 2b: entries NE..NE+3 of the longer lists, all in flight together (the
         // continuation table is a few MB: L2 / Infinity Cache hits)
         uint4 ca0[U], ca1[U], cb0[U], cb1[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {  // branch-free as above: shorter lists read the table's zero piece
-            ca0[k] = idx.cont[ra[k].n > (uint32_t)NE ? ra[k].off : idx.zero_piece];
-            ca1[k] = idx.cont[ra[k].n > (uint32_t)NE + 2u ? ra[k].off + 1u : idx.zero_piece];
-            cb0[k] = idx.cont[rb[k].n > (uint32_t)NE ? rb[k].off : idx.zero_piece];
-            cb1[k] = idx.cont[rb[k].n > (uint32_t)NE + 2u ? rb[k].off + 1u : idx.zero_piece];
+            ca0[k] = load_piece(idx.cont, ra[k].n > (uint32_t)NE ? ra[k].off : idx.zero_piece);
+            ca1[k] = load_piece(idx.cont, ra[k].n > (uint32_t)NE + 2u ? ra[k].off + 1u : idx.zero_piece);
+            cb0[k] = load_piece(idx.cont, rb[k].n > (uint32_t)NE ? rb[k].off : idx.zero_piece);
+            cb1[k] = load_piece(idx.cont, rb[k].n > (uint32_t)NE + 2u ? rb[k].off + 1u : idx.zero_piece);
         }
+        __builtin_amdgcn_sched_barrier(0);
         TEC_CLK(2);  // continuation gathers
         // ---- stage 3: edge tests over the records, distinct names, count
 #pragma unroll
@@ -670,7 +698,9 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                 if (hs.classes & (1u << TEC_CLASS_ENHANCER)) ++n_enh;
                 continue;
             }
+#ifdef TEC_DIAGNOSTICS
             if (mute) continue;
+#endif
             // all adds of the unit first, then one look at the words they replaced
             uint32_t o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0;
             const uint32_t o0 = fast.add(hs.h0);
@@ -703,18 +733,17 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     store_hist(hist, words, slabs + (size_t)blockIdx.x * words);
     TEC_CLK(5);  // final flush
     TEC_CLK_STORE;
+#ifdef TEC_DIAGNOSTICS
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     n_assigned = wave_sum(n_assigned);
-    n_lowq = wave_sum(n_lowq);
-    n_bad = wave_sum(n_bad);
-    n_qc = wave_sum(n_qc);
     n_enh = wave_sum(n_enh);
     if ((threadIdx.x & 63) == 0) {
         if (n_assigned) atomicAdd(&stats[1], (unsigned long long)n_assigned);
-        if (n_lowq) atomicAdd(&stats[2], (unsigned long long)n_lowq);
-        if (n_bad) atomicAdd(&stats[3], (unsigned long long)n_bad);
-        if (n_qc) atomicAdd(&stats[4], (unsigned long long)n_qc);
+        if (w_lowq) atomicAdd(&stats[2], (unsigned long long)w_lowq);
+        if (w_bad) atomicAdd(&stats[3], (unsigned long long)w_bad);
+        if (w_qc) atomicAdd(&stats[4], (unsigned long long)w_qc);
         if (n_enh) atomicAdd(&stats[5], (unsigned long long)n_enh);
     }
 }

@@ -184,7 +184,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const size_t o_cb = align_up(o_ent + std::max<uint64_t>(n_entries_kept, 1) * sizeof(tec_entry), 256);
     const size_t o_cn = align_up(o_cb + n_chrom * sizeof(uint32_t), 256);
     // compact bin records for the bulk kernel (coordinates relative to bin start - 1, 16 bits)
-    const int rec_ne = shift <= 15 ? ctx->rec_ne_wanted : 0;
+    // records only while their table stays below 4 GiB (the kernel addresses it with 32-bit byte offsets)
+    const int rec_ne = shift <= 15 && n_bins < (1ull << 26) ? ctx->rec_ne_wanted : 0;
     const size_t rec_words = rec_ne ? 2 + 2 * (size_t)rec_ne : 0;
     const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
     std::vector<uint32_t> recs((size_t)(n_bins + 1) * rec_words + 4, 0u);  // + one all-zero record (idx.zero_rec)
@@ -196,8 +197,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
             const uint32_t cnt = bin_off[b + 1] - bin_off[b];
             if (cnt > (uint32_t)rec_ne) pieces += (cnt - rec_ne + 1) / 2;
         }
-        if (pieces >= 0xFFFFFFF0ull)
-            return tec_fail(ctx, TEC_EOVERFLOW, "tec_index_build: %llu continuation pieces exceed 32-bit offsets",
+        if (pieces >= (1ull << 28) - 16)  // 16 bytes each, 32-bit byte offsets
+            return tec_fail(ctx, TEC_EOVERFLOW, "tec_index_build: %llu continuation pieces exceed 32-bit byte offsets",
                             (unsigned long long)pieces);
         cont.assign((size_t)(pieces + 2) * 4, 0u);  // two zero pieces at the end (idx.zero_piece; a lane may read one piece too far)
         n_pieces = pieces;
