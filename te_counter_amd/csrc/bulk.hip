@@ -28,7 +28,6 @@ constexpr int kBlock = 1024;
 #ifndef TEC_REC_WAVES
 #define TEC_REC_WAVES 4  // min waves per SIMD the record kernel is compiled for (8: two workgroups per CU)
 #endif
-constexpr uint32_t kLdsBytes = 75 * 1024;      // per workgroup: two workgroups (+ their static LDS) fit a CU's 160 KiB
 constexpr uint32_t kLdsMaxBytes = 154 * 1024;  // one workgroup per CU (room for the static chromosome table)
 constexpr uint32_t kChromLds = 512;            // the record kernel keeps every chromosome's {base, bins} in LDS
 
@@ -827,15 +826,14 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const uint64_t chunk = (uint64_t)unroll * kBlock;
     const uint64_t want = (n + chunk - 1) / chunk;
     const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0 || ctx->force_mixed;
-    // LDS histogram: every name if that fits (two workgroups per CU up to 75 KiB each, else one
-    // workgroup with up to 154 KiB); beyond that the coldest names spill to global atomics.
-    uint32_t budget = ctx->lds_bytes;
-    if (budget == 0) budget = (size_t)ctx->idx.n_names * 2 <= kLdsBytes ? kLdsBytes : kLdsMaxBytes;
+    // LDS histogram: every name if that fits (up to 154 KiB); beyond that the coldest names spill
+    // to global atomics.  One 1024-thread workgroup per CU: the kernels are compiled for four
+    // waves per SIMD (~100 VGPRs), so a second workgroup would not be co-resident anyway.
+    uint32_t budget = ctx->lds_bytes ? ctx->lds_bytes : kLdsMaxBytes;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, budget / 2);
     const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // as the kernels compute it
     const size_t lds = (size_t)words * 4;
-    const unsigned wg_per_cu = lds <= kLdsBytes ? 2u : 1u;
-    const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * wg_per_cu);
+    const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu);
     // one histogram row per workgroup; reduce_slabs_kernel folds them into the count vector
     const size_t slab_bytes = (size_t)grid * words * sizeof(uint32_t);
     if (slab_bytes > ctx->slab_cap) {
