@@ -80,6 +80,11 @@ struct tec_ctx {
     double kernel_ms = 0.0, reduce_ms = 0.0;
     uint32_t* d_slabs = nullptr;  // [workgroups x histogram words] per-workgroup histogram rows of a launch
     size_t slab_cap = 0;
+    // partitioned pipeline (bulk.hip): items grouped by genome window, window x workgroup offsets, chunk lists
+    int partition = 0;
+    int part_wshift = 0;
+    void *d_part_items = nullptr, *d_part_h = nullptr, *d_part_pm = nullptr;
+    size_t part_items_cap = 0, part_h_cap = 0, part_pm_cap = 0;
     uint64_t kernel_launches = 0;
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
