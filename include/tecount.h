@@ -227,6 +227,11 @@ int tec_sc_end(tec_ctx* ctx);
 typedef struct tec_bam tec_bam;
 int tec_bam_open(const char* path, int n_threads, tec_bam** out);
 void tec_bam_close(tec_bam* r);
+/* Raw DEFLATE (RFC 1951) of one BGZF block body into exactly out_len bytes: the decoder the BAM
+ * reader uses in place of pysam / htslib (te_count.py:65, 190, 351); use_zlib != 0 runs zlib's
+ * inflate instead (the referee in tests).  TEC_OK, or TEC_EINVAL for a malformed / short / long stream. */
+int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_len, int use_zlib);
+
 const char* tec_bam_last_error(const tec_bam* r);
 int tec_bam_n_refs(const tec_bam* r);
 const char* tec_bam_ref_name(const tec_bam* r, int i);

@@ -65,6 +65,7 @@ _SIGNATURES = {
     'tec_sc_stats': (C.c_int, [_p, C.POINTER(ScStats)]),
     'tec_sc_end': (C.c_int, [_p]),
     'tec_write_dense_tsv': (C.c_int, [C.c_char_p, C.c_char_p, _u64, C.c_uint32, C.c_uint32, C.c_char_p, _p, _u64, _p, _p, _p]),
+    'tec_inflate_raw': (C.c_int, [_p, _u64, _p, _u64, C.c_int]),
     'tec_bam_open': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_p)]),
     'tec_bam_close': (None, [_p]),
     'tec_bam_last_error': (C.c_char_p, [_p]),

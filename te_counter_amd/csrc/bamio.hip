@@ -12,11 +12,42 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "inflate_fast.h"
 #include "tecount_internal.h"
+
+// A growable byte window that is never zero-filled (std::vector::resize would touch every byte).
+struct ByteBuf {
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ~ByteBuf() { free(p); }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+    void drop_front(size_t k) {
+        if (k == 0) return;
+        memmove(p, p + k, n - k);
+        n -= k;
+    }
+    bool grow(size_t add) {
+        if (n + add > cap) {
+            const size_t c = std::max(cap * 2, n + add + 4096);
+            uint8_t* q = static_cast<uint8_t*>(realloc(p, c));
+            if (!q) return false;
+            p = q;
+            cap = c;
+        }
+        n += add;
+        return true;
+    }
+};
 
 struct tec_bam {
     FILE* fh = nullptr;
@@ -25,9 +56,13 @@ struct tec_bam {
     std::vector<std::string> ref_names;
     std::vector<uint32_t> ref_lens;
     // uncompressed stream window
-    std::vector<uint8_t> buf;
+    ByteBuf buf;
     size_t buf_pos = 0;
     bool eof = false;
+    // compressed bytes read ahead from the file (BAM only)
+    ByteBuf raw;
+    size_t raw_pos = 0;
+    bool file_eof = false;
     int n_threads = 4;
     uint64_t n_records = 0;
     // SAM text state
@@ -45,36 +80,77 @@ int bam_fail(tec_bam* r, int code, const std::string& msg) {
 }
 
 struct RawBlock {
-    std::vector<uint8_t> cdata;
+    size_t off = 0;  // of the DEFLATE body inside r->raw
+    size_t clen = 0;
     uint32_t isize = 0;
     size_t out_off = 0;
 };
+
+// One raw-DEFLATE block body -> exactly isize bytes.  The fast decoder first (inflate_fast.h, ~2x
+// zlib on BAM payloads); anything it refuses goes to zlib, whose verdict is final.
+// TEC_INFLATE=zlib forces zlib.
+bool inflate_one(const uint8_t* in, size_t in_len, uint8_t* out, size_t isize, tec_inflate::Tables* tabs) {
+    static const bool force_zlib = [] {
+        const char* e = getenv("TEC_INFLATE");
+        return e && !strcmp(e, "zlib");
+    }();
+    if (!force_zlib && tec_inflate::inflate_block(in, in_len, out, isize, tabs)) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(in);
+    zs.avail_in = (uInt)in_len;
+    zs.next_out = out;
+    zs.avail_out = (uInt)isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+// At least `need` unread compressed bytes in r->raw (file reads of 16 MiB); false at end of file.
+bool raw_ensure(tec_bam* r, size_t need) {
+    while (r->raw.size() - r->raw_pos < need) {
+        if (r->file_eof) return false;
+        const size_t want = std::max<size_t>(need, 16u << 20);
+        const size_t old = r->raw.size();
+        if (!r->raw.grow(want)) return false;
+        const size_t got = fread(r->raw.data() + old, 1, want, r->fh);
+        r->raw.n = old + got;
+        if (got < want) r->file_eof = true;
+    }
+    return true;
+}
 
 // Reads up to max_blocks BGZF blocks and appends their inflated bytes to r->buf.
 int refill(tec_bam* r, size_t max_blocks) {
     if (r->eof) return 0;
     // drop what has been consumed
     if (r->buf_pos) {
-        r->buf.erase(r->buf.begin(), r->buf.begin() + r->buf_pos);
+        r->buf.drop_front(r->buf_pos);
         r->buf_pos = 0;
+    }
+    if (r->raw_pos) {
+        r->raw.drop_front(r->raw_pos);
+        r->raw_pos = 0;
     }
     std::vector<RawBlock> blocks;
     size_t total = 0;
     while (blocks.size() < max_blocks) {
-        uint8_t h[18];
-        size_t got = fread(h, 1, 18, r->fh);
-        if (got == 0) {
-            r->eof = true;
-            break;
+        if (!raw_ensure(r, 18)) {
+            if (r->raw.size() - r->raw_pos == 0) {
+                r->eof = true;
+                break;
+            }
+            return bam_fail(r, TEC_EINVAL, "not a BGZF block (truncated or not a BAM file)");
         }
-        if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
+        const uint8_t* h = r->raw.data() + r->raw_pos;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
             return bam_fail(r, TEC_EINVAL, "not a BGZF block (truncated or not a BAM file)");
         const unsigned xlen = h[10] | (h[11] << 8);
+        if (!raw_ensure(r, 12 + (size_t)xlen)) return bam_fail(r, TEC_EINVAL, "truncated BGZF extra field");
+        h = r->raw.data() + r->raw_pos;  // the window may have moved
+        const uint8_t* extra = h + 12;
         // the BC subfield is normally first; walk the extra field to be safe
-        std::vector<uint8_t> extra(xlen);
-        memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, r->fh) != xlen - 6)
-            return bam_fail(r, TEC_EINVAL, "truncated BGZF extra field");
         int bsize = -1;
         for (size_t o = 0; o + 4 <= xlen;) {
             const unsigned slen = extra[o + 2] | (extra[o + 3] << 8);
@@ -84,38 +160,32 @@ int refill(tec_bam* r, size_t max_blocks) {
         if (bsize < 0) return bam_fail(r, TEC_EINVAL, "BGZF block without BC subfield");
         const long clen = (long)bsize + 1 - 12 - (long)xlen - 8;
         if (clen < 0) return bam_fail(r, TEC_EINVAL, "corrupt BGZF block size");
+        if (!raw_ensure(r, (size_t)bsize + 1)) return bam_fail(r, TEC_EINVAL, "truncated BGZF block");
+        const uint8_t* tail = r->raw.data() + r->raw_pos + 12 + xlen + (size_t)clen;
         RawBlock b;
-        b.cdata.resize((size_t)clen);
-        uint8_t tail[8];
-        if ((clen && fread(b.cdata.data(), 1, (size_t)clen, r->fh) != (size_t)clen) || fread(tail, 1, 8, r->fh) != 8)
-            return bam_fail(r, TEC_EINVAL, "truncated BGZF block");
+        b.off = r->raw_pos + 12 + xlen;
+        b.clen = (size_t)clen;
         b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
         b.out_off = total;
         total += b.isize;
-        blocks.push_back(std::move(b));
+        r->raw_pos += (size_t)bsize + 1;
+        blocks.push_back(b);
     }
     if (blocks.empty()) return 0;
     const size_t base = r->buf.size();
-    r->buf.resize(base + total);
+    if (!r->buf.grow(total)) return bam_fail(r, TEC_EINVAL, "out of memory for the inflate window");
     const int nt = std::max(1, std::min<int>(r->n_threads, (int)blocks.size()));
     std::vector<int> status(nt, 0);
+    const uint8_t* raw = r->raw.data();
+    uint8_t* dst = r->buf.data() + base;
     auto work = [&](int t) {
-        for (size_t i = t; i < blocks.size(); i += nt) {
-            RawBlock& b = blocks[i];
+        std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
+        // contiguous shares: neighbouring blocks stay on one core
+        const size_t per = (blocks.size() + nt - 1) / nt, a = (size_t)t * per, z = std::min(blocks.size(), a + per);
+        for (size_t i = a; i < z; ++i) {
+            const RawBlock& b = blocks[i];
             if (b.isize == 0) continue;
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) {
-                status[t] = 1;
-                return;
-            }
-            zs.next_in = b.cdata.data();
-            zs.avail_in = (uInt)b.cdata.size();
-            zs.next_out = r->buf.data() + base + b.out_off;
-            zs.avail_out = b.isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) {
+            if (!inflate_one(raw + b.off, b.clen, dst + b.out_off, b.isize, tabs.get())) {
                 status[t] = 1;
                 return;
             }
@@ -361,6 +431,24 @@ int sam_record(tec_bam* r, uint64_t o, const OutArrays& a) {
 }
 
 }  // namespace
+
+extern "C" int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_len, int use_zlib) {
+    if ((!in && in_len) || (!out && out_len)) return TEC_EINVAL;
+    if (use_zlib) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return TEC_EINVAL;
+        zs.next_in = const_cast<Bytef*>(in);
+        zs.avail_in = (uInt)in_len;
+        zs.next_out = out;
+        zs.avail_out = (uInt)out_len;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        return rc == Z_STREAM_END && zs.avail_out == 0 ? TEC_OK : TEC_EINVAL;
+    }
+    std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
+    return tec_inflate::inflate_block(in, in_len, out, out_len, tabs.get()) ? TEC_OK : TEC_EINVAL;
+}
 
 extern "C" const char* tec_bam_last_error(const tec_bam* r) { return r ? r->err.c_str() : g_bam_err.c_str(); }
 

@@ -1,0 +1,98 @@
+"""The BAM reader's own DEFLATE decoder (csrc/inflate_fast.h) against zlib: every stream zlib can
+produce for blocks up to 64 KiB must decode to the same bytes, and damaged streams must be
+refused (or decode to something zlib agrees with) without touching memory outside the buffers."""
+
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from te_counter_amd import _lib
+
+
+def _inflate(comp, n, use_zlib=0):
+    lib = _lib.load()
+    out = (C.c_uint8 * (n + 64))()
+    guard = bytes(range(64))
+    C.memmove(C.addressof(out) + n, guard, 64)
+    rc = lib.tec_inflate_raw(comp, len(comp), out, n, use_zlib)
+    assert bytes(out[n:n + 64]) == guard, 'wrote past the output buffer'
+    return rc, bytes(out[:n])
+
+
+def _payloads():
+    rng = np.random.default_rng(5)
+    yield b''
+    yield b'a'
+    yield b'abc' * 7
+    yield bytes(65280)                                   # one long run (dist 1 matches)
+    yield bytes(rng.integers(0, 256, 65280, dtype=np.uint8))   # incompressible -> stored blocks
+    yield bytes(rng.integers(0, 4, 65280, dtype=np.uint8))     # 2-bit alphabet: short codes, long matches
+    yield bytes(rng.integers(65, 69, 30000, dtype=np.uint8)) + bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    yield (b'ACGT' * 25 + b'\xff' * 100 + b'NH:i:1\x00') * 300  # BAM-like records
+    # BAM-like with real entropy in seq/qual
+    recs = bytearray()
+    for i in range(260):
+        recs += b'\x10\x01\x00\x00' + int(i * 37).to_bytes(4, 'little') + b'A00123:45:HXX:1:%d:%d\x00' % (1100 + i, i * 7)
+        recs += bytes(rng.integers(0, 256, 50, dtype=np.uint8)) + bytes(rng.integers(2, 41, 100, dtype=np.uint8)) + b'NHC\x01HIC\x01'
+    yield bytes(recs)
+    for n in (1, 2, 3, 7, 8, 9, 255, 256, 257, 258, 259, 1000, 32768, 32769, 65535):
+        yield bytes(rng.integers(0, 7, n, dtype=np.uint8))
+    for _ in range(40):
+        n = int(rng.integers(1, 65281))
+        k = int(rng.integers(1, 257))
+        yield bytes(rng.integers(0, k, n, dtype=np.uint8))
+
+
+@pytest.mark.parametrize('level,strategy', [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (0, zlib.Z_DEFAULT_STRATEGY)])
+def test_matches_zlib(level, strategy):
+    for data in _payloads():
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        comp = co.compress(data) + co.flush()
+        rc, got = _inflate(comp, len(data))
+        assert rc == 0 and got == data, (level, strategy, len(data))
+        # wrong expected sizes are refused
+        if len(data) > 1:
+            assert _inflate(comp, len(data) - 1)[0] != 0
+        assert _inflate(comp, len(data) + 1)[0] != 0
+
+
+def test_multi_block_streams():
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        parts, comp = [], b''
+        for _ in range(int(rng.integers(2, 6))):
+            d = bytes(rng.integers(0, int(rng.integers(2, 200)), int(rng.integers(1, 12000)), dtype=np.uint8))
+            parts.append(d)
+            comp += co.compress(d) + co.flush(zlib.Z_FULL_FLUSH if rng.random() < 0.5 else zlib.Z_SYNC_FLUSH)
+        comp += co.flush()
+        data = b''.join(parts)
+        rc, got = _inflate(comp, len(data))
+        assert rc == 0 and got == data
+
+
+def test_damaged_streams_never_disagree_with_zlib():
+    rng = np.random.default_rng(13)
+    base = bytes(rng.integers(0, 20, 20000, dtype=np.uint8))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(base) + co.flush()
+    accepted = 0
+    for trial in range(600):
+        b = bytearray(comp)
+        kind = trial % 3
+        if kind == 0:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            del b[int(rng.integers(1, len(b))):]
+        else:
+            for _ in range(4):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        rc, got = _inflate(bytes(b), len(base))
+        zrc, zgot = _inflate(bytes(b), len(base), use_zlib=1)
+        if rc == 0:  # whatever the fast decoder accepts, zlib decodes to the same bytes
+            accepted += 1
+            assert zrc == 0 and zgot == got
+    assert accepted < 600
