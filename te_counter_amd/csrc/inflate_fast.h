@@ -268,6 +268,30 @@ inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t
                 ip += (63 - bitcnt) >> 3;
                 bitcnt |= 56;
                 uint32_t e = lit[bitbuf & ((1u << kLitBits) - 1u)];
+                // up to three first-level literals from one refill (<= 33 of the >= 56 bits)
+                if ((e & 0xF0u) == kKindLiteral) {
+                    bitbuf >>= (e & 15u);
+                    bitcnt -= (int)(e & 15u);
+                    *op++ = (uint8_t)(e >> 16);
+                    e = lit[bitbuf & ((1u << kLitBits) - 1u)];
+                    if ((e & 0xF0u) == kKindLiteral) {
+                        bitbuf >>= (e & 15u);
+                        bitcnt -= (int)(e & 15u);
+                        *op++ = (uint8_t)(e >> 16);
+                        e = lit[bitbuf & ((1u << kLitBits) - 1u)];
+                        if ((e & 0xF0u) == kKindLiteral) {
+                            bitbuf >>= (e & 15u);
+                            bitcnt -= (int)(e & 15u);
+                            *op++ = (uint8_t)(e >> 16);
+                            continue;
+                        }
+                    }
+                    // e is the next symbol's first-level entry, not consumed yet: top the buffer up
+                    // (a length/distance pair needs up to 48 bits)
+                    bitbuf |= load64(ip) << bitcnt;
+                    ip += (63 - bitcnt) >> 3;
+                    bitcnt |= 56;
+                }
                 if ((e & 0xF0u) == kKindLink) {
                     e = lit[(e >> 16) + ((bitbuf >> kLitBits) & ((1u << ((e >> 8) & 31u)) - 1u))];
                     bitbuf >>= kLitBits;
@@ -275,15 +299,8 @@ inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t
                 }
                 bitbuf >>= (e & 15u);
                 bitcnt -= (int)(e & 15u);
-                if ((e & 0xF0u) == kKindLiteral) {
+                if ((e & 0xF0u) == kKindLiteral) {  // a long-code literal
                     *op++ = (uint8_t)(e >> 16);
-                    // a second literal from the bits already in the buffer (>= 41 left)
-                    uint32_t e2 = lit[bitbuf & ((1u << kLitBits) - 1u)];
-                    if ((e2 & 0xF0u) == kKindLiteral) {
-                        bitbuf >>= (e2 & 15u);
-                        bitcnt -= (int)(e2 & 15u);
-                        *op++ = (uint8_t)(e2 >> 16);
-                    }
                     continue;
                 }
                 if ((e & 0xF0u) != kKindBase) {
