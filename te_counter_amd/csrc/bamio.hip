@@ -14,7 +14,11 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <vector>
 
 #include "inflate_fast.h"
@@ -59,7 +63,10 @@ struct tec_bam {
     ByteBuf buf;
     size_t buf_pos = 0;
     bool eof = false;
-    // compressed bytes read ahead from the file (BAM only)
+    // compressed bytes (BAM only): the whole file mapped read-only, or -- when it cannot be
+    // mapped (a pipe) -- a window read ahead with fread
+    const uint8_t* map = nullptr;
+    size_t map_len = 0;
     ByteBuf raw;
     size_t raw_pos = 0;
     bool file_eof = false;
@@ -107,8 +114,11 @@ bool inflate_one(const uint8_t* in, size_t in_len, uint8_t* out, size_t isize, t
     return rc == Z_STREAM_END && zs.avail_out == 0;
 }
 
-// At least `need` unread compressed bytes in r->raw (file reads of 16 MiB); false at end of file.
+const uint8_t* raw_base(const tec_bam* r) { return r->map ? r->map : r->raw.data(); }
+
+// At least `need` unread compressed bytes at raw_base() + raw_pos; false at end of file.
 bool raw_ensure(tec_bam* r, size_t need) {
+    if (r->map) return r->map_len - r->raw_pos >= need;
     while (r->raw.size() - r->raw_pos < need) {
         if (r->file_eof) return false;
         const size_t want = std::max<size_t>(need, 16u << 20);
@@ -120,35 +130,31 @@ bool raw_ensure(tec_bam* r, size_t need) {
     }
     return true;
 }
+size_t raw_left(const tec_bam* r) { return (r->map ? r->map_len : r->raw.size()) - r->raw_pos; }
 
-// Reads up to max_blocks BGZF blocks and appends their inflated bytes to r->buf.
-int refill(tec_bam* r, size_t max_blocks) {
+// Finds up to max_blocks BGZF blocks at the read position; *total = their inflated size.
+int discover_blocks(tec_bam* r, size_t max_blocks, std::vector<RawBlock>* blocks, size_t* total) {
+    blocks->clear();
+    *total = 0;
     if (r->eof) return 0;
-    // drop what has been consumed
-    if (r->buf_pos) {
-        r->buf.drop_front(r->buf_pos);
-        r->buf_pos = 0;
-    }
-    if (r->raw_pos) {
+    if (!r->map && r->raw_pos) {
         r->raw.drop_front(r->raw_pos);
         r->raw_pos = 0;
     }
-    std::vector<RawBlock> blocks;
-    size_t total = 0;
-    while (blocks.size() < max_blocks) {
+    while (blocks->size() < max_blocks) {
         if (!raw_ensure(r, 18)) {
-            if (r->raw.size() - r->raw_pos == 0) {
+            if (raw_left(r) == 0) {
                 r->eof = true;
                 break;
             }
             return bam_fail(r, TEC_EINVAL, "not a BGZF block (truncated or not a BAM file)");
         }
-        const uint8_t* h = r->raw.data() + r->raw_pos;
+        const uint8_t* h = raw_base(r) + r->raw_pos;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
             return bam_fail(r, TEC_EINVAL, "not a BGZF block (truncated or not a BAM file)");
         const unsigned xlen = h[10] | (h[11] << 8);
         if (!raw_ensure(r, 12 + (size_t)xlen)) return bam_fail(r, TEC_EINVAL, "truncated BGZF extra field");
-        h = r->raw.data() + r->raw_pos;  // the window may have moved
+        h = raw_base(r) + r->raw_pos;  // the window may have moved
         const uint8_t* extra = h + 12;
         // the BC subfield is normally first; walk the extra field to be safe
         int bsize = -1;
@@ -161,45 +167,36 @@ int refill(tec_bam* r, size_t max_blocks) {
         const long clen = (long)bsize + 1 - 12 - (long)xlen - 8;
         if (clen < 0) return bam_fail(r, TEC_EINVAL, "corrupt BGZF block size");
         if (!raw_ensure(r, (size_t)bsize + 1)) return bam_fail(r, TEC_EINVAL, "truncated BGZF block");
-        const uint8_t* tail = r->raw.data() + r->raw_pos + 12 + xlen + (size_t)clen;
+        const uint8_t* tail = raw_base(r) + r->raw_pos + 12 + xlen + (size_t)clen;
         RawBlock b;
         b.off = r->raw_pos + 12 + xlen;
         b.clen = (size_t)clen;
         b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-        b.out_off = total;
-        total += b.isize;
+        b.out_off = *total;
+        *total += b.isize;
         r->raw_pos += (size_t)bsize + 1;
-        blocks.push_back(b);
+        blocks->push_back(b);
     }
-    if (blocks.empty()) return 0;
+    return blocks->empty() ? 0 : 1;
+}
+
+// Reads up to max_blocks BGZF blocks and appends their inflated bytes to r->buf (header parsing;
+// the record path inflates inside read_chunk below).
+int refill(tec_bam* r, size_t max_blocks) {
+    if (r->buf_pos) {
+        r->buf.drop_front(r->buf_pos);
+        r->buf_pos = 0;
+    }
+    std::vector<RawBlock> blocks;
+    size_t total = 0;
+    const int k = discover_blocks(r, max_blocks, &blocks, &total);
+    if (k <= 0) return k;
     const size_t base = r->buf.size();
     if (!r->buf.grow(total)) return bam_fail(r, TEC_EINVAL, "out of memory for the inflate window");
-    const int nt = std::max(1, std::min<int>(r->n_threads, (int)blocks.size()));
-    std::vector<int> status(nt, 0);
-    const uint8_t* raw = r->raw.data();
-    uint8_t* dst = r->buf.data() + base;
-    auto work = [&](int t) {
-        std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
-        // contiguous shares: neighbouring blocks stay on one core
-        const size_t per = (blocks.size() + nt - 1) / nt, a = (size_t)t * per, z = std::min(blocks.size(), a + per);
-        for (size_t i = a; i < z; ++i) {
-            const RawBlock& b = blocks[i];
-            if (b.isize == 0) continue;
-            if (!inflate_one(raw + b.off, b.clen, dst + b.out_off, b.isize, tabs.get())) {
-                status[t] = 1;
-                return;
-            }
-        }
-    };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
-        for (auto& x : th) x.join();
-    }
-    for (int t = 0; t < nt; ++t)
-        if (status[t]) return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
+    std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
+    for (const RawBlock& b : blocks)
+        if (b.isize && !inflate_one(raw_base(r) + b.off, b.clen, r->buf.data() + base + b.out_off, b.isize, tabs.get()))
+            return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
     return 1;
 }
 
@@ -208,7 +205,7 @@ bool ensure(tec_bam* r, size_t need, int* rc) {
     *rc = 0;
     while (r->buf.size() - r->buf_pos < need) {
         if (r->eof) return false;
-        const int k = refill(r, 512);
+        const int k = refill(r, 8);
         if (k < 0) {
             *rc = k;
             return false;
@@ -464,9 +461,21 @@ extern "C" int tec_bam_open(const char* path, int n_threads, tec_bam** out) {
     const size_t got = fread(m, 1, 4, fh);
     fseek(fh, 0, SEEK_SET);
     r->is_bam = got >= 2 && m[0] == 31 && m[1] == 139;
+    if (r->is_bam) {  // map the file when it can be mapped (no copy through the page cache into a user buffer)
+        struct stat st;
+        if (fstat(fileno(fh), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fh), 0);
+            if (m != MAP_FAILED) {
+                r->map = static_cast<const uint8_t*>(m);
+                r->map_len = (size_t)st.st_size;
+                (void)madvise(m, r->map_len, MADV_SEQUENTIAL);
+            }
+        }
+    }
     const int rc = r->is_bam ? read_bam_header(r) : read_sam_header(r);
     if (rc != TEC_OK) {
         g_bam_err = r->err;
+        if (r->map) munmap(const_cast<uint8_t*>(r->map), r->map_len);
         fclose(fh);
         delete r;
         return rc;
@@ -477,6 +486,7 @@ extern "C" int tec_bam_open(const char* path, int n_threads, tec_bam** out) {
 
 extern "C" void tec_bam_close(tec_bam* r) {
     if (!r) return;
+    if (r->map) munmap(const_cast<uint8_t*>(r->map), r->map_len);
     if (r->fh) fclose(r->fh);
     delete r;
 }
@@ -484,6 +494,143 @@ extern "C" void tec_bam_close(tec_bam* r) {
 extern "C" int tec_bam_n_refs(const tec_bam* r) { return r ? (int)r->ref_names.size() : -1; }
 extern "C" const char* tec_bam_ref_name(const tec_bam* r, int i) {
     return (r && i >= 0 && (size_t)i < r->ref_names.size()) ? r->ref_names[i].c_str() : nullptr;
+}
+
+// One record (p points at its block_size field, the whole record is in memory) -> row w of the SoA.
+bool extract_record(const uint8_t* rec, uint64_t w, const OutArrays& a) {
+    const uint8_t* p = rec + 4;
+    const uint32_t bs = le32(rec);
+    const uint8_t* e = p + bs;
+    const int32_t refid = (int32_t)le32(p);
+    const int32_t p0 = (int32_t)le32(p + 4);
+    const unsigned l_name = p[8];
+    const unsigned n_cig = le16(p + 12);
+    const uint32_t l_seq = le32(p + 16);
+    const uint8_t* name = p + 32;
+    const uint8_t* cig = name + l_name;
+    const uint8_t* aux = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
+    if (aux > e) return false;
+    int64_t reflen = 0;
+    for (unsigned c = 0; c < n_cig; ++c) {
+        const uint32_t v = le32(cig + 4 * c);
+        const unsigned op = v & 15u;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;  // M D N = X
+    }
+    a.tid[w] = refid;
+    a.pos[w] = p0;
+    a.end[w] = n_cig ? (int32_t)(p0 + reflen) : INT32_MIN;  // pysam: reference_end is None without a CIGAR
+    a.flag[w] = le16(p + 14);
+    a.mapq[w] = p[9];
+    if (a.qkey) a.qkey[w] = mate_key_hash((const char*)name, l_name ? l_name - 1 : 0);
+    if (a.tagflags) {
+        uint8_t tf = 0;
+        memset(a.cb24 + 24 * w, 0, 24);
+        memset(a.ub24 + 24 * w, 0, 24);
+        scan_aux(aux, e, a.cb24 + 24 * w, a.ub24 + 24 * w, &tf);
+        a.tagflags[w] = tf;
+    }
+    return true;
+}
+
+// One chunk: up to 512 BGZF blocks in contiguous shares, one per thread.  A thread inflates its
+// share, then -- holding the baton {next record start, records so far} from the thread before it --
+// walks the record boundaries of its share while the bytes are still in its cache, hands the baton
+// on, and extracts the fields of its own records.  Only the boundary walk is sequential, and it
+// runs on cache-hot data (a single-threaded walk over the whole inflated window was memory-bound
+// and capped the decoder at ~5 M records/s however many threads inflated).
+int read_chunk(tec_bam* r, uint64_t max_left, uint64_t first_row, const OutArrays& a, uint64_t* got) {
+    *got = 0;
+    if (r->buf_pos) {
+        r->buf.drop_front(r->buf_pos);
+        r->buf_pos = 0;
+    }
+    std::vector<RawBlock> blocks;
+    size_t total = 0;
+    const int k = discover_blocks(r, 512, &blocks, &total);
+    if (k < 0) return k;
+    if (k == 0) return TEC_OK;
+    const size_t base = r->buf.size();
+    if (!r->buf.grow(total)) return bam_fail(r, TEC_EINVAL, "out of memory for the inflate window");
+    const int nt = std::max(1, std::min<int>(r->n_threads, (int)blocks.size()));
+    const size_t per = (blocks.size() + nt - 1) / nt;
+    struct Baton {
+        size_t pos = 0;
+        uint64_t count = 0;
+        bool ready = false;
+        bool bad = false;  // a share before this one failed: nothing downstream is trusted
+    };
+    std::vector<Baton> baton(nt + 1);
+    baton[0].pos = 0;  // the window was compacted: the first unparsed record starts at 0
+    baton[0].ready = true;
+    std::vector<int> status(nt, 0);  // 1 inflate failed, 2 corrupt record size, 3 corrupt record layout
+    std::mutex mu;
+    std::condition_variable cv;
+    const uint8_t* raw = raw_base(r);
+    uint8_t* win = r->buf.data();
+    auto work = [&](int t) {
+        const size_t b0 = (size_t)t * per, b1 = std::min(blocks.size(), b0 + per);
+        if (b0 < b1) {
+            std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
+            for (size_t i = b0; i < b1 && !status[t]; ++i) {
+                const RawBlock& b = blocks[i];
+                if (b.isize && !inflate_one(raw + b.off, b.clen, win + base + b.out_off, b.isize, tabs.get())) status[t] = 1;
+            }
+        }
+        // bytes [0, share_end) are inflated once the baton arrives (every earlier thread passes it after its own inflate)
+        const size_t share_end = b1 < blocks.size() ? base + blocks[b1].out_off : base + total;
+        Baton in;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return baton[t].ready; });
+            in = baton[t];
+        }
+        std::vector<size_t> offs;
+        size_t pos = in.pos;
+        uint64_t count = in.count;
+        if (!status[t] && !in.bad && b0 < b1) {
+            while (count < max_left && pos + 4 <= share_end) {
+                const uint32_t bs = le32(win + pos);
+                if (bs < 32) {
+                    status[t] = 2;
+                    break;
+                }
+                if (pos + 4 + (size_t)bs > share_end) break;  // completed by a later share (or the next chunk)
+                offs.push_back(pos);
+                pos += 4 + (size_t)bs;
+                ++count;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            baton[t + 1].pos = pos;
+            baton[t + 1].count = count;
+            baton[t + 1].bad = in.bad || status[t] != 0;
+            baton[t + 1].ready = true;
+        }
+        cv.notify_all();
+        uint64_t w = first_row + in.count;
+        for (size_t o : offs) {
+            if (!extract_record(win + o, w++, a)) {
+                status[t] = 3;
+                return;
+            }
+        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (int t = 0; t < nt; ++t) {
+        if (status[t] == 1) return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
+        if (status[t] == 2) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
+        if (status[t] == 3) return bam_fail(r, TEC_EINVAL, "corrupt BAM record layout");
+    }
+    r->buf_pos = baton[nt].pos;
+    *got = baton[nt].count;
+    return TEC_OK;
 }
 
 extern "C" int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int32_t* pos, int32_t* end, uint16_t* flag,
@@ -505,83 +652,29 @@ extern "C" int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int3
         r->n_records += o;
         return TEC_OK;
     }
-    std::vector<size_t> offs;
-    while (o < max_records) {
-        int rc;
-        if (!ensure(r, 4, &rc)) {
-            if (rc) return rc;
-            if (r->buf.size() - r->buf_pos != 0) return bam_fail(r, TEC_EINVAL, "truncated BAM record");
-            break;
-        }
-        const uint32_t bs0 = le32(r->buf.data() + r->buf_pos);
-        if (bs0 < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
-        if (!ensure(r, 4 + (size_t)bs0, &rc)) return bam_fail(r, rc ? rc : TEC_EINVAL, "truncated BAM record");
-        // phase 1 (sequential, cheap): boundaries of the complete records already inflated
-        offs.clear();
+    // (A) complete records that are already in the window (a previous call stopped at max_records
+    // in the middle of a chunk): sequential, at most one chunk's worth
+    {
         size_t pos_b = r->buf_pos;
         const size_t have = r->buf.size();
-        while (o + offs.size() < max_records && pos_b + 4 <= have) {
+        while (o < max_records && pos_b + 4 <= have) {
             const uint32_t bs = le32(r->buf.data() + pos_b);
             if (bs < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
             if (pos_b + 4 + (size_t)bs > have) break;
-            offs.push_back(pos_b);
+            if (!extract_record(r->buf.data() + pos_b, o, a)) return bam_fail(r, TEC_EINVAL, "corrupt BAM record layout");
+            ++o;
             pos_b += 4 + (size_t)bs;
         }
-        // phase 2 (parallel): field extraction into the SoA rows
-        const size_t nrec = offs.size();
-        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)r->n_threads, nrec / 4096));
-        std::vector<int> bad(nt, 0);
-        auto work = [&](int t) {
-            for (size_t k = (size_t)t; k < nrec; k += (size_t)nt) {
-                const uint8_t* p = r->buf.data() + offs[k] + 4;
-                const uint32_t bs = le32(p - 4);
-                const uint8_t* e = p + bs;
-                const uint64_t w = o + k;
-                const int32_t refid = (int32_t)le32(p);
-                const int32_t p0 = (int32_t)le32(p + 4);
-                const unsigned l_name = p[8];
-                const unsigned n_cig = le16(p + 12);
-                const uint32_t l_seq = le32(p + 16);
-                const uint8_t* name = p + 32;
-                const uint8_t* cig = name + l_name;
-                const uint8_t* aux = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
-                if (aux > e) {
-                    bad[t] = 1;
-                    return;
-                }
-                int64_t reflen = 0;
-                for (unsigned c = 0; c < n_cig; ++c) {
-                    const uint32_t v = le32(cig + 4 * c);
-                    const unsigned op = v & 15u;
-                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;  // M D N = X
-                }
-                tid[w] = refid;
-                pos[w] = p0;
-                end[w] = n_cig ? (int32_t)(p0 + reflen) : INT32_MIN;  // pysam: reference_end is None without a CIGAR
-                flag[w] = le16(p + 14);
-                mapq[w] = p[9];
-                if (qkey) qkey[w] = mate_key_hash((const char*)name, l_name ? l_name - 1 : 0);
-                if (tagflags) {
-                    uint8_t tf = 0;
-                    memset(cb24 + 24 * w, 0, 24);
-                    memset(ub24 + 24 * w, 0, 24);
-                    scan_aux(aux, e, cb24 + 24 * w, ub24 + 24 * w, &tf);
-                    tagflags[w] = tf;
-                }
-            }
-        };
-        if (nt == 1) {
-            work(0);
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
-            for (auto& x : th) x.join();
-        }
-        for (int t = 0; t < nt; ++t)
-            if (bad[t]) return bam_fail(r, TEC_EINVAL, "corrupt BAM record layout");
-        o += nrec;
         r->buf_pos = pos_b;
     }
+    // (B) chunks of up to 512 BGZF blocks: inflate, boundary scan and field extraction fused per thread
+    while (o < max_records && !r->eof) {
+        uint64_t got = 0;
+        const int rc = read_chunk(r, max_records - o, o, a, &got);
+        if (rc != TEC_OK) return rc;
+        o += got;
+    }
+    if (r->eof && o < max_records && r->buf.size() - r->buf_pos != 0) return bam_fail(r, TEC_EINVAL, "truncated BAM record");
     *n_out = o;
     r->n_records += o;
     return TEC_OK;

@@ -105,3 +105,43 @@ def test_not_a_bam(tmp_path):
     p.write_bytes(b'\x1f\x8b' + b'junkjunkjunkjunkjunkjunk')
     with pytest.raises(IOError):
         bam.open_alignment(str(p))
+
+
+def test_chunked_reader_threads_and_batches(tmp_path):
+    """A file of several 512-block chunks: every thread count and batch size must give the same rows
+    (records straddle BGZF blocks, thread shares and chunks; batches end in the middle of chunks)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_e2e
+    n = 330_001
+    rng = np.random.default_rng(8)
+    tid = rng.integers(0, 3, n).astype(np.int32)
+    pos = rng.integers(0, 1 << 28, n).astype(np.int32)
+    flag = rng.integers(0, 4096, n).astype(np.uint16)
+    mapq = rng.integers(0, 256, n).astype(np.uint8)
+    path = str(tmp_path / 'big.bam')
+    bench_e2e.write_bam_fast(path, ['chr1', 'chr2', 'chrUn'], tid, pos, flag, mapq, pair_names=True)
+    assert os.path.getsize(path) > 40_000_000  # > 512 blocks of 64 KiB
+    ref = None
+    for threads, batch in [(1, 1 << 22), (3, 77_777), (8, 1000), (8, 1 << 22), (5, 130_000)]:
+        src = bam.BamSource(path, batch_size=batch, threads=threads)
+        cols = [[], [], [], [], [], []]
+        for b in src.batches(prefetch=0):
+            for c, v in zip(cols, (b.tid, b.pos, b.end, b.flag, b.mapq, b.qkey)):
+                c.append(v.copy())
+        src.close()
+        got = [np.concatenate(c) for c in cols]
+        assert len(got[0]) == n
+        assert (got[0] == tid).all() and (got[1] == pos).all() and (got[2] == pos + 100).all()
+        assert (got[3] == flag).all() and (got[4] == mapq).all()
+        if ref is None:
+            ref = got[5]
+        assert (got[5] == ref).all()
+    # a file cut in the middle of a block, and one cut in the middle of a record, are refused
+    data = open(path, 'rb').read()
+    cut = str(tmp_path / 'cut.bam')
+    open(cut, 'wb').write(data[:len(data) // 2])
+    with pytest.raises(IOError):
+        for _ in bam.BamSource(cut, threads=4).batches(prefetch=0):
+            pass
