@@ -40,7 +40,8 @@ def main():
     ap.add_argument('--genes', type=int, default=40000, help='genes in the synthetic annotation (experiments)')
     ap.add_argument('--cpu-sample', type=int, default=25_000_000, help='units timed on the CPU oracle (0 = skip)')
     ap.add_argument('--traffic', default=None, help='HBM bytes per launch from rocprofv3 --pmc passes; default: profiles/traffic.json entry of this workload')
-    ap.add_argument('--host-stream', action='store_true', help='also time the pinned-host -> HBM -> kernel path (PCIe-inclusive; reported beside, never as value)')
+    ap.add_argument('--host-stream', action='store_true', help='(default at N=1) also time the pinned-host -> HBM -> kernel path (PCIe-inclusive; reported beside, never as value)')
+    ap.add_argument('--no-host-stream', action='store_true', help='skip the PCIe-inclusive measurement')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -156,7 +157,7 @@ def main():
         tr = out['roofline']['traffic']
         if tr:  # the rate at which the measured L2<->fabric bytes move: what actually bounds the shuffled case
             out['roofline']['traffic_GBps'] = round(tr / (avg_ms * 1e-3) / 1e9, 1)
-        if args.host_stream and world == 1:
+        if not args.no_host_stream and world == 1:
             out['pcie_inclusive'] = host_stream(eng, units, n_units, rec_per_unit)
         if args.cpu_sample and world == 1:
             out['cpu_baseline'] = cpu_baseline(ann, units, min(args.cpu_sample, n_units), rec_per_unit, eng)

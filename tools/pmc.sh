@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 $BARGS > $OUT/p$i.log 2>&1 || { echo "pass $i ($grp) failed"; tail -3 $OUT/p$i.log; continue; }
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-host-stream $BARGS > $OUT/p$i.log 2>&1 || { echo "pass $i ($grp) failed"; tail -3 $OUT/p$i.log; continue; }
   python3 - $OUT/p$i/pmc_counter_collection.csv <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)

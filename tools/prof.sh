@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 echo "$*" > $OUT/bench_args.txt
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 0 $*"
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-host-stream $*"
 run() { # name, counters...
   local name=$1; shift
   echo "[prof] $name: $*"

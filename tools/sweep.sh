@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for v in "$@"; do
   echo "== $v"
-  timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 $v 2>/dev/null | python3 -c "
+  timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-host-stream $v 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

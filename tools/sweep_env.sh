@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 VAR=$1; VALS=$2; shift 2
 for v in $VALS; do
   echo "== $VAR=$v $*"
-  env $VAR=$v timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 "$@" 2>/dev/null | python3 -c "
+  env $VAR=$v timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-host-stream "$@" 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

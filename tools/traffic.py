@@ -32,7 +32,7 @@ def main():
     src, tag, key = sys.argv[1], sys.argv[2], sys.argv[3]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {'tag': tag, 'workload': key, 'bench_args': open(os.path.join(src, 'bench_args.txt')).read().strip(),
-           'command': 'rocprofv3 <flags> -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 <bench_args>'}
+           'command': 'rocprofv3 <flags> -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-host-stream <bench_args>'}
     stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
