@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "tecount_internal.h"
 
 namespace {
@@ -1099,10 +1101,10 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     // spans: ~span_div per workgroup, each a whole number of chunks
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
-    TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
     const bool rec_ok = ctx->kernel_variant == 2 && ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3;
     unsigned rows = grid;  // histogram rows the reduce kernel folds
     if (ctx->partition && rec_ok && unroll == 2 && (n >= (1u << 16) || ctx->partition == 2) && n < 0xFFFF0000ull) {
+        TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
         // ---- partitioned pipeline: histogram, scan, scatter, count over the items
         int wshift = ctx->part_wshift;
         if (wshift <= 0) {
@@ -1155,19 +1157,23 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
                            (const int32_t*)nullptr, (const uint16_t*)nullptr, (const uint8_t*)nullptr, (uint64_t)0,
                            ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, (uint64_t)1, (uint32_t)ctx->aggregate,
                            ctx->d_slabs);
-    } else
-    hipLaunchKernelGGL(pick_kernel(mixed, unroll, ctx->kernel_variant == 2 && ctx->idx.n_chrom <= kChromLds ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid), dim3(kBlock), lds, ctx->s_compute, ctx->idx, u.chrom, u.p1,
-                       u.p2, u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                       (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, ctx->d_slabs);
-    TEC_HIP(ctx, hipGetLastError());
-    TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
-    {
-        const unsigned split = std::max(1u, std::min(rows / 16u, 32u));  // >= 16 rows per thread
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((words + 255u) / 256u, split), dim3(256), 0, ctx->s_compute,
-                           ctx->d_slabs, words, words, rows, ctx->d_counts);
+        TEC_HIP(ctx, hipGetLastError());
+        TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
+    } else {
+        // start / stop timestamps ride on the dispatch itself: no barrier packets between the launches
+        hipExtLaunchKernelGGL(pick_kernel(mixed, unroll, rec_ok ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid),
+                              dim3(kBlock), (uint32_t)lds, ctx->s_compute, ev.start, ev.stop, 0u, ctx->idx, u.chrom, u.p1, u.p2,
+                              u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
+                              (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, ctx->d_slabs);
         TEC_HIP(ctx, hipGetLastError());
     }
-    TEC_HIP(ctx, hipEventRecord(ev.reduced, ctx->s_compute));
+    {
+        const unsigned split = std::max(1u, std::min(rows / 16u, 32u));  // >= 16 rows per thread
+        hipExtLaunchKernelGGL(reduce_slabs_kernel, dim3((words + 255u) / 256u, split), dim3(256), 0u, ctx->s_compute,
+                              (hipEvent_t) nullptr, ev.reduced, 0u, (const uint32_t*)ctx->d_slabs, words, words, rows,
+                              ctx->d_counts);
+        TEC_HIP(ctx, hipGetLastError());
+    }
     ++ctx->kernel_launches;
     return TEC_OK;
 }
