@@ -4,7 +4,13 @@
 epochs).  Times tec_sc_* end to end from host SoA batches (H2D copies included) and checks a
 reduced-size run of the same generator against the Python oracle.
 
-    python tools/bench_sc.py [--records N] [--check 150000]
+    python tools/bench_sc.py [--records N] [--check 150000] [--pinned]
+
+Multi-GPU: the single-cell path runs as REPLICAS (the spill-epoch boundaries need
+the global running count of new (CB,UB) keys in file order, and the path is bound by the host side,
+not the GPU).  Launched with `python -m torch.distributed.run --nproc-per-node N tools/bench_sc.py`,
+every rank counts its own sample (seed + rank) on its own GPU; rank 0 prints the aggregate rate over
+the slowest rank's time.  TEC_BENCH_BACKEND=gloo rehearses that on a box with fewer GPUs than ranks.
 """
 import argparse
 import json
@@ -47,10 +53,24 @@ def main():
     ap.add_argument('--cells', type=int, default=10000)
     ap.add_argument('--check', type=int, default=150000, help='records of the reduced-size oracle check (0 = skip)')
     ap.add_argument('--strand', action='store_true')
+    ap.add_argument('--pinned', action='store_true', help='host batches in pinned memory (H2D at PCIe speed)')
     args = ap.parse_args()
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('WORLD_SIZE', 1), ('LOCAL_RANK', 0)))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get('TEC_BENCH_BACKEND', 'nccl')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend != 'nccl':
+            local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, **({'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}))
+        if rank:
+            args.check = 0
     from te_counter_amd import Engine, synth
     ann = synth.make_annotation('hg38')
-    eng = Engine(0)
+    eng = Engine(local)
     eng.upload_index(ann.flat)
     res = {}
     if args.check:
@@ -77,16 +97,33 @@ def main():
             sys.exit('PARITY FAILURE in the reduced-size single-cell check')
         eng.upload_index(ann.flat)
     t0 = time.time()
-    arrays, wl, tables = synth.make_sc_arrays(ann, args.records, n_cells=args.cells)
+    arrays, wl, tables = synth.make_sc_arrays(ann, args.records, n_cells=args.cells, seed=2004 + rank)
     res['gen_s'] = round(time.time() - t0, 1)
+    if args.pinned:
+        import torch
+        keep = {k: torch.from_numpy(v).pin_memory() for k, v in arrays.items() if isinstance(v, np.ndarray)}
+        arrays = dict(arrays, **{k: t_.numpy() for k, t_ in keep.items()})
     n = len(arrays['pos'])
     run(eng, {k: v[:1 << 20] for k, v in arrays.items()}, wl, tables, args.cells, args.strand, 10_000_000)  # warm-up
+    if dist:
+        dist.barrier()
     out, st, t, _ = run(eng, arrays, wl, tables, args.cells, args.strand, 10_000_000)
-    res.update({'metric': 'Mreads/s single-cell (--sc --se) end to end from host SoA batches', 'records': n,
-                'value': round(n / t['total'] / 1e6, 2), 'unit': 'Mreads/s', 'seconds': {k: round(v, 3) for k, v in t.items()},
-                'stats': st, 'cells_with_hits': int(len(out['cells'])), 'coo_nnz': int(len(out['coo_cell']))})
-    print(json.dumps(res))
+    total = t['total']
+    if dist:
+        import torch
+        tt = torch.tensor([total], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total = float(tt.item())
+    if rank == 0:
+        res.update({'metric': 'Mreads/s single-cell (--sc --se) end to end from host SoA batches', 'records': n * world,
+                    'n_gpus': world, 'parallelism': 'replicas' if world > 1 else 'single', 'pinned': bool(args.pinned),
+                    'value': round(n * world / total / 1e6, 2), 'unit': 'Mreads/s',
+                    'seconds': {k: round(v, 3) for k, v in t.items()},
+                    'stats': st, 'cells_with_hits': int(len(out['cells'])), 'coo_nnz': int(len(out['coo_cell']))})
+        print(json.dumps(res))
     eng.close()
+    if dist:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
