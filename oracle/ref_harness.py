@@ -235,6 +235,29 @@ def run_make_snrnps(genome, gencode_gz):
                  'name': r['name'], 'type': r['type'], 'ensg': r['ensg']} for r in gl.linearData]
 
 
+def run_make_enh(genome, bed_gz):
+    """The reference's make_enh (te_count/genome/make.py:129-171) on a LOCAL copy of the FANTOM5
+    enhancer BED it would download (same os proxy as run_make_genes_tes; make_enh also joins paths)."""
+    import shutil
+    tc = load_reference()
+    mk = sys.modules['te_count.genome.make']
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(bed_gz, os.path.join(td, f'enh_{genome}.bed.gz'))
+        proxy = types.SimpleNamespace(system=lambda cmd: 0,
+                                      path=types.SimpleNamespace(dirname=lambda p: td, realpath=os.path.realpath, join=os.path.join))
+        real_os, stdout, stderr = mk.os, sys.stdout, sys.stderr
+        mk.os = proxy
+        sys.stdout, sys.stderr = io.StringIO(), io.StringIO()
+        try:
+            mk.make_enh(genome, _quiet_log())
+        finally:
+            mk.os = real_os
+            sys.stdout, sys.stderr = stdout, stderr
+        gl = tc.miniglbase.glload(os.path.join(td, f'{genome}_enhancers.glb'))
+        return [{'chr': r['loc']['chr'], 'left': r['loc']['left'], 'right': r['loc']['right'],
+                 'name': r['name'], 'type': r['type'], 'ensg': r['ensg']} for r in gl.linearData]
+
+
 def run_make_genes_tes(genome, gencode_gz, rmsk_gz):
     """The reference's make_genes_tes (te_count/genome/make.py:15-127) on LOCAL copies of the two
     files it would download: its module-level `os` is swapped for a proxy whose system() does

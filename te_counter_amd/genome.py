@@ -183,3 +183,34 @@ def make_snrnps(gencode_path, filename_for_index):
     out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
     FlatIndex.from_features(feats).save(out)
     return out
+
+
+def enhancers_features(genome, bed_path):
+    """make_enh (make.py:129-171) over a local copy of the FANTOM5 enhancer BED the reference
+    downloads (F5.<genome>.enhancers.bed.gz): every line is a row (no header is skipped), columns
+    0-2 are chr / left / right through `location()` (chr normalised, location.py:20-32); name and
+    ensg are 'F5enh_<genome>_<chr>_<left>_<right>', type 'enhancer', no strand key; chromosomes
+    outside {X, Y, 1..29} are dropped."""
+    import gzip
+    feats = []
+    opener = gzip.open if str(bed_path).endswith('.gz') else open
+    with opener(bed_path, 'rt') as fh:
+        for line in fh:
+            col = line.rstrip('\r\n').split('\t')
+            if len(col) < 3:
+                continue
+            chrom = index_chrom_key(col[0])
+            if chrom not in CHR_SET_CUSTOM:
+                continue
+            left, right = int(col[1]), int(col[2])
+            name = 'F5enh_{0}_{1}_{2}_{3}'.format(genome, chrom, left, right)
+            feats.append({'chr': chrom, 'left': left, 'right': right, 'name': name, 'type': 'enhancer', 'ensg': name})
+    return feats
+
+
+def make_enhancers(genome, bed_path, filename_for_index):
+    feats = enhancers_features(genome, bed_path)
+    print('\nAdded {:,} features'.format(len(feats)))
+    out = filename_for_index if str(filename_for_index).endswith('.tecidx') else str(filename_for_index) + '.tecidx'
+    FlatIndex.from_features(feats).save(out)
+    return out

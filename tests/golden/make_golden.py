@@ -179,6 +179,21 @@ def main():
         dump('genes_tes_rows_%s' % genome, {'kind': 'genes_tes', 'genome': genome, 'expected': {'rows': rh.run_make_genes_tes(
             genome, os.path.join(HERE, 'genes_tes_gencode.gtf.gz'), os.path.join(HERE, 'genes_tes_rmsk.txt.gz'))}})
 
+    # te_genome -m enhancers from a local FANTOM5-style BED and the reference's rows
+    import numpy as _np
+    _rng = _np.random.default_rng(5)
+    _chroms = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chrUn_KI270742v1', 'chr10', 'chr22_KI270879v1_alt', 'chr29', 'chr30']
+    _lines = []
+    for _i in range(60):
+        _c = _chroms[_i % len(_chroms)]
+        _l = int(_rng.integers(1000, 100000))
+        _r = _l + int(_rng.integers(50, 900))
+        _lines.append('\t'.join([_c, str(_l), str(_r), '%s:%d-%d' % (_c, _l, _r), '0', '.', str(_l + 10), str(_l + 11), '0,0,0',
+                                 '2', '20,30', '0,%d' % (_r - _l - 30)]))
+    with gzip.GzipFile(os.path.join(HERE, 'enhancers_f5.bed.gz'), 'wb', mtime=0) as fh:
+        fh.write(('\n'.join(_lines) + '\n').encode())
+    dump('enhancers_rows_hg38', {'kind': 'enhancers', 'genome': 'hg38', 'expected': {'rows': rh.run_make_enh(
+        'hg38', os.path.join(HERE, 'enhancers_f5.bed.gz'))}})
     with gzip.GzipFile(os.path.join(HERE, 'snrnps_gencode.gtf.gz'), 'wb', mtime=0) as fh:
         fh.write(dg.make_gencode_text(43, 120, named_frac=1.0).encode())  # make_snrnps needs gene_name everywhere
     dump('snrnps_rows_hg38', {'kind': 'snrnps', 'genome': 'hg38', 'expected': {'rows': rh.run_make_snrnps(

@@ -151,3 +151,24 @@ def test_snrnps_builder_matches_reference_rows():
     rows = genome.snrnps_features(os.path.join(GOLDEN_DIR, 'snrnps_gencode.gtf.gz'))
     assert rows == g['expected']['rows'] and len(rows) > 5
     assert all(r['name'].startswith('snRNA-') for r in rows)
+
+
+def test_enhancers_builder_matches_reference_rows(tmp_path):
+    """make_enh (make.py:129-171) over a local FANTOM5-style BED: rows identical to the reference's,
+    and bin/te_genome -m enhancers --bed writes an index of them."""
+    import subprocess
+    import sys
+    from conftest import GOLDEN_DIR, ROOT
+    from te_counter_amd import genome
+    from te_counter_amd.index import FlatIndex
+    g = load_golden('enhancers_rows_hg38')
+    bed = os.path.join(GOLDEN_DIR, 'enhancers_f5.bed.gz')
+    rows = genome.enhancers_features('hg38', bed)
+    assert rows == g['expected']['rows'] and len(rows) == 36
+    assert all(r['type'] == 'enhancer' and 'strand' not in r for r in rows)
+    env = dict(os.environ, TE_COUNT_GENOME_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bin', 'te_genome'), '-g', 'hg38', '-m', 'enhancers', '--bed', bed],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    built = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith('.tecidx')]
+    assert len(built) == 1 and len(FlatIndex.load(built[0])) == 36
