@@ -11,9 +11,15 @@
 //   edge tests   T1: p1 >= Gl and p1+1 <= Gr ; T2: p2-1 >= Gl and p2 <= Gr   (te_count.py:122,125 / 237,240)
 //   counting     if any hit has a countable class: +1 for every DISTINCT name among the hits
 //                (te_count.py:132-144, 245-257); only-'enhancer' hits crash the reference (:145-147)
-// Distinct names need no per-lane buffer: entries are sorted by name id inside a fine bin, so
-// duplicates inside one bin scan are adjacent, and a hit from the second edge's bin is checked
-// against the first bin by re-scanning it (both lists are short and L1-resident by then).
+//
+// Kernels in this file:
+//   count_bulk_rec_kernel  the product kernel: one compact 32-byte bin record per edge lookup,
+//                          continuation pieces for longer lists, six-slot register hit set, packed
+//                          16-bit LDS histogram with carry bookkeeping, histogram rows + reduce
+//   reduce_slabs_kernel    folds the per-workgroup histogram rows into the u64 count vector
+//   count_bulk_kernel      the CSR walk (indexes without records: bins wider than 32 kb, more than
+//                          512 chromosomes); also the exact path's walk_hits lives here
+//   part_*_kernel          the experimental partitioned pipeline (TEC_PARTITION, off by default)
 #include <algorithm>
 #include <cstdlib>
 
@@ -35,7 +41,7 @@ constexpr uint32_t kNoName = 0xFFFFFFFFu;
 #define TEC_PM_CHUNKS 32u
 constexpr int kBlock = 1024;
 #ifndef TEC_REC_WAVES
-#define TEC_REC_WAVES 4  // min waves per SIMD the record kernel is compiled for (8: two workgroups per CU)
+#define TEC_REC_WAVES 4  // min waves per SIMD the record kernel is compiled for (one 1024-thread workgroup per CU)
 #endif
 constexpr uint32_t kLdsMaxBytes = 154 * 1024;  // one workgroup per CU (room for the static chromosome table)
 constexpr uint32_t kChromLds = 512;            // the record kernel keeps every chromosome's {base, bins} in LDS
