@@ -574,19 +574,24 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     uint32_t* pm = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(p1));
     const uint32_t xcd = blockIdx.x & 7u;
     uint32_t c_pos = 0, c_rem = 0;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t c_next = (blockIdx.x >> 3) * (kBlock / 64u) + wave_id;
+    const uint32_t c_step = (gridDim.x >> 3) * (kBlock / 64u);
+    const uint32_t pm_nchunks = ITEMS ? pm[TEC_PM_NCHUNKS + xcd] : 0u, pm_cbase = ITEMS ? pm[TEC_PM_CBASE + xcd] : 0u;
     const uint32_t binmask = (1u << idx.shift) - 1u;
     for (;;) {
         uint64_t base;
         uint32_t left;  // units of this piece
         if (ITEMS) {
             if (c_rem == 0) {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(&pm[TEC_PM_TICK + xcd], 1u);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                if (c >= pm[TEC_PM_NCHUNKS + xcd]) break;
-                const uint32_t ci = pm[TEC_PM_CBASE + xcd] + c;
-                c_pos = pm[TEC_PM_CHUNKS + 2u * ci];
-                c_rem = pm[TEC_PM_CHUNKS + 2u * ci + 1u];
+                // static striping of the XCD's chunk list over its waves: a shared ticket counter
+                // (4096 waves on one line of memory-side atomics, ~100 ns each) serialized the kernel
+                const uint32_t c = c_next;
+                c_next += c_step;
+                if (c >= pm_nchunks) break;
+                const uint2 ch2 = *reinterpret_cast<const uint2*>(&pm[TEC_PM_CHUNKS + 2u * (pm_cbase + c)]);
+                c_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch2.x);
+                c_rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch2.y);
                 if (c_rem == 0) continue;
             }
             base = c_pos;
@@ -940,26 +945,35 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// One workgroup.  Row w of H (one count per workgroup of the passes) -> exclusive offsets inside
-// the window, window starts in wstart[0..W]; every window's items are cut into chunks of kPartChunk,
-// hottest window first, and the chunks are dealt to the eight XCD lists in turn: all XCDs work
-// through the same window at the same time (a window parked on ONE XCD made that L2 serve all the
-// requests for the window's hot lines: 2x slower than no partition at all).  pm: TEC_PM_* layout.
-__global__ __launch_bounds__(kBlock) void part_scan_kernel(uint32_t* H, uint32_t W, uint32_t G, uint32_t* wstart_out, uint32_t* pm) {
+// One wave per window: row w of H (one count per workgroup of the passes, G a multiple of 512)
+// -> exclusive offsets inside the window, the window's size to wsize_out[w].
+__global__ __launch_bounds__(kBlock) void part_rowscan_kernel(uint32_t* H, uint32_t W, uint32_t G, uint32_t* wsize_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+    if (w >= W) return;
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < G; g0 += 512) {  // eight consecutive counts per lane: one round trip per 512
+        uint4* p = reinterpret_cast<uint4*>(H + (size_t)w * G + g0 + lane * 8u);
+        uint4 a = p[0], b = p[1];
+        const uint32_t s0 = a.x, s1 = s0 + a.y, s2 = s1 + a.z, s3 = s2 + a.w, s4 = s3 + b.x, s5 = s4 + b.y, s6 = s5 + b.z,
+                       s7 = s6 + b.w;
+        const uint32_t inc = wave_incl_scan(s7);
+        const uint32_t base = carry + inc - s7;
+        p[0] = make_uint4(base, base + s0, base + s1, base + s2);
+        p[1] = make_uint4(base + s3, base + s4, base + s5, base + s6);
+        carry += (uint32_t)__shfl(inc, 63, 64);
+    }
+    if (lane == 0) wsize_out[w] = carry;
+}
+
+// One workgroup.  Window sizes -> window starts in wstart_out[0..W); every window's items are cut
+// into chunks of kPartChunk, hottest window first, and the chunks are dealt to the eight XCD lists
+// in turn: all XCDs work through the same window at the same time.  pm: TEC_PM_* layout.
+__global__ __launch_bounds__(kBlock) void part_scan_kernel(const uint32_t* wsize_in, uint32_t W, uint32_t* wstart_out, uint32_t* pm) {
     __shared__ uint32_t wsize[kPartMaxW], wsc[kPartMaxW], wrank[kPartMaxW];
     __shared__ uint32_t total_chunks;
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    for (uint32_t w = wave; w < W; w += kBlock / 64) {  // one wave per row, coalesced
-        uint32_t carry = 0;
-        for (uint32_t g0 = 0; g0 < G; g0 += 64) {
-            const uint32_t g = g0 + lane;
-            const uint32_t c = g < G ? H[(size_t)w * G + g] : 0u;
-            const uint32_t inc = wave_incl_scan(c);
-            if (g < G) H[(size_t)w * G + g] = carry + inc - c;
-            carry += (uint32_t)__shfl(inc, 63, 64);
-        }
-        if (lane == 0) wsize[w] = carry;
-    }
+    const uint32_t t = threadIdx.x;
+    if (t < kPartMaxW) wsize[t] = t < W ? wsize_in[t] : 0u;
     __syncthreads();
     // exclusive scan of the window sizes (W <= 1024: one value per thread)
     wsc[t] = t < W ? wsize[t] : 0u;
@@ -1119,9 +1133,9 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
         }
         while (((ctx->n_bins >> wshift) + 1) > kPartMaxW) ++wshift;
         const uint32_t W = (uint32_t)(ctx->n_bins >> wshift) + 1;
-        const uint32_t G = 2u * (uint32_t)ctx->n_cu;  // two 1024-thread workgroups of the passes per CU
+        const uint32_t G = (2u * (uint32_t)ctx->n_cu + 511u) / 512u * 512u;  // ~two workgroups of the passes per CU; whole 512s for the row scan
         const size_t need_items = (size_t)n * sizeof(uint4);
-        const size_t need_h = ((size_t)W * G + kPartMaxW + 8) * sizeof(uint32_t);  // + the window starts
+        const size_t need_h = ((size_t)W * G + 2 * kPartMaxW + 8) * sizeof(uint32_t);  // + the window starts and sizes
         const size_t need_pm = (size_t)(TEC_PM_CHUNKS + 2 * (n / kPartChunk + W + 64)) * sizeof(uint32_t);
         if (need_items > ctx->part_items_cap || need_h > ctx->part_h_cap || need_pm > ctx->part_pm_cap) {
             TEC_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
@@ -1154,7 +1168,10 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
         uint32_t* wstart = H + (size_t)W * G;
         hipLaunchKernelGGL(part_pass_kernel<false>, dim3(G), dim3(kBlock), 0, ctx->s_compute, ctx->idx, u.chrom, u.p1, u.p2,
                            u.flag, u.mapq, n, ctx->mapq_min, ctx->d_stats, H, wstart, W, wshift, items);
-        hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(kBlock), 0, ctx->s_compute, H, W, G, wstart, pm);
+        uint32_t* wsize = wstart + kPartMaxW;
+        hipLaunchKernelGGL(part_rowscan_kernel, dim3((W + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, ctx->s_compute, H, W, G,
+                           wsize);
+        hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(kBlock), 0, ctx->s_compute, (const uint32_t*)wsize, W, wstart, pm);
         hipLaunchKernelGGL(part_pass_kernel<true>, dim3(G), dim3(kBlock), 0, ctx->s_compute, ctx->idx, u.chrom, u.p1, u.p2,
                            u.flag, u.mapq, n, ctx->mapq_min, ctx->d_stats, H, wstart, W, wshift, items);
         TEC_HIP(ctx, hipGetLastError());
