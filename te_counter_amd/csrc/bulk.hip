@@ -815,15 +815,23 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
 #endif
     if (!ITEMS && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+    // tallies: waves -> workgroup (LDS) -> five global adds per workgroup (4 096 waves adding to one
+    // line of memory-side atomics would queue behind each other at the end of the launch)
+    __shared__ uint32_t tally[5];
+    if (threadIdx.x < 5) tally[threadIdx.x] = 0;
+    __syncthreads();
     n_assigned = wave_sum(n_assigned);
     n_enh = wave_sum(n_enh);
     if ((threadIdx.x & 63) == 0) {
-        if (n_assigned) atomicAdd(&stats[1], (unsigned long long)n_assigned);
-        if (w_lowq) atomicAdd(&stats[2], (unsigned long long)w_lowq);
-        if (w_bad) atomicAdd(&stats[3], (unsigned long long)w_bad);
-        if (w_qc) atomicAdd(&stats[4], (unsigned long long)w_qc);
-        if (n_enh) atomicAdd(&stats[5], (unsigned long long)n_enh);
+        if (n_assigned) atomicAdd(&tally[0], n_assigned);
+        if (w_lowq) atomicAdd(&tally[1], w_lowq);
+        if (w_bad) atomicAdd(&tally[2], w_bad);
+        if (w_qc) atomicAdd(&tally[3], w_qc);
+        if (n_enh) atomicAdd(&tally[4], n_enh);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 5 && tally[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
