@@ -137,6 +137,26 @@ __device__ __forceinline__ void wave_add(unsigned long long* ctr, bool pred) {
     if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
 }
 
+// Tallies of a whole block: waves add into LDS, one thread per counter adds to global memory.
+// (One global atomic per WAVE on the few adjacent stat counters -- millions of memory-side atomics
+// on one 64-byte line, ~7 ns each -- was a third of the ingest time of a 50 M-record run.)
+template <int N>
+struct BlockTally {
+    uint32_t* lds;  // N counters in LDS, zeroed by begin()
+    __device__ __forceinline__ void begin() {
+        if (threadIdx.x < N) lds[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void add(int k, bool pred) {
+        const unsigned long long m = __ballot(pred);
+        if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&lds[k], (uint32_t)__builtin_popcountll(m));
+    }
+    __device__ __forceinline__ void end(unsigned long long* const* dst) {
+        __syncthreads();
+        if (threadIdx.x < N && lds[threadIdx.x]) atomicAdd(dst[threadIdx.x], (unsigned long long)lds[threadIdx.x]);
+    }
+};
+
 // te_count.py:394-433, in the reference's order.
 __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* __restrict__ cls,
                                  const uint16_t* __restrict__ flag, const uint8_t* __restrict__ mapq,
@@ -145,6 +165,9 @@ __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* _
                                  const uint8_t* __restrict__ cls_skip,
                                  uint32_t n_class, uint32_t* live, uint32_t* bcid_out, unsigned long long* stat) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t tally_lds[4];
+    BlockTally<4> tally{tally_lds};
+    tally.begin();
     bool qc = false, lowq = false, badbc = false, skipc = false, ok = false;
     if (i < n) {
         const unsigned fl = flag[i];
@@ -177,10 +200,12 @@ __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* _
         }
         live[i] = ok ? 1u : 0u;
     }
-    wave_add(&stat[ST_QCFAIL], qc);
-    wave_add(&stat[ST_LOWQ], lowq);
-    wave_add(&stat[ST_BADBC], badbc);
-    wave_add(&stat[ST_SKIPCHROM], skipc);
+    tally.add(0, qc);
+    tally.add(1, lowq);
+    tally.add(2, badbc);
+    tally.add(3, skipc);
+    unsigned long long* const dst[4] = {&stat[ST_QCFAIL], &stat[ST_LOWQ], &stat[ST_BADBC], &stat[ST_SKIPCHROM]};
+    tally.end(dst);
 }
 
 __global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, uint64_t out_base, const uint32_t* __restrict__ live,
@@ -213,10 +238,20 @@ __global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, uint64_t out_ba
         b |= __shfl_down(b, off, 64);
         c |= __shfl_down(c, off, 64);
     }
+    // block-level OR in LDS, then one global atomic per word and block
+    __shared__ unsigned long long or_lds[3];
+    if (threadIdx.x < 3) or_lds[threadIdx.x] = 0;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
-        if (a) atomicOr(&stat[ST_OR0], (unsigned long long)a);
-        if (b) atomicOr(&stat[ST_OR1], (unsigned long long)b);
-        if (c) atomicOr(&stat[ST_OR2], (unsigned long long)c);
+        if (a) atomicOr(&or_lds[0], (unsigned long long)a);
+        if (b) atomicOr(&or_lds[1], (unsigned long long)b);
+        if (c) atomicOr(&or_lds[2], (unsigned long long)c);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && or_lds[threadIdx.x]) {
+        // skip the global atomic when it would not change anything (the common case after the first blocks)
+        unsigned long long* g = &stat[ST_OR0 + threadIdx.x];
+        if ((or_lds[threadIdx.x] & ~__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) atomicOr(g, or_lds[threadIdx.x]);
     }
 }
 
@@ -389,7 +424,12 @@ __global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* 
                                 const uint32_t* __restrict__ emit_off, uint64_t* keys, uint32_t* cellhits,
                                 unsigned long long* stat, unsigned long long* n_assigned) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nq) return;
+    // tallies per block (see BlockTally): [0] assigned, [1] hits on a feature without a strand
+    __shared__ uint32_t tally_lds[2];
+    BlockTally<2> tally{tally_lds};
+    if (!EMIT) tally.begin();
+    bool did_assign = false, did_nostrand = false;
+    if (t < nq) {
     const uint32_t i = qrec[t];
     const int kl = klass[i];
     const int chrom = cls_chrom[kl >> 1];
@@ -427,12 +467,12 @@ __global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* 
         if (classes) {
             if (!EMIT) {
                 atomicAdd(&cellhits[bc[i]], 1u);  // self.barcodes[barcode] += 1 (te_count.py:653-655)
-                if (nostrand) atomicAdd(&stat[ST_NOSTRAND], 1ull);  // KeyError: 'strand' (te_count.py:661)
+                did_nostrand = nostrand;  // KeyError: 'strand' (te_count.py:661)
             }
             const bool gene = classes & (1u << TEC_CLASS_GENE);
             const bool other = classes & ((1u << TEC_CLASS_TE) | (1u << TEC_CLASS_ENHANCER));
             if (gene || other) {
-                if (!EMIT) atomicAdd(n_assigned, 1ull);
+                did_assign = true;
                 const uint32_t rs = (uint32_t)(kl & 1);
                 const uint64_t cell = (uint64_t)bc[i] << 32;
                 uint32_t last = 0xFFFFFFFFu;
@@ -472,6 +512,13 @@ __global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* 
         }
     }
     if (!EMIT) n_emit[t] = emitted;
+    }
+    if (!EMIT) {
+        tally.add(0, did_assign);
+        tally.add(1, did_nostrand);
+        unsigned long long* const dst[2] = {n_assigned, &stat[ST_NOSTRAND]};
+        tally.end(dst);
+    }
 }
 
 __global__ void map_names_kernel(uint64_t n, uint64_t* keys, const uint32_t* __restrict__ int2ext) {
