@@ -405,18 +405,25 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
     store_hist(hist, words, slabs + (size_t)blockIdx.x * words);
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+    // tallies: waves -> workgroup (LDS) -> five global adds per workgroup (see count_bulk_rec_kernel)
+    __shared__ uint32_t tally[5];
+    if (threadIdx.x < 5) tally[threadIdx.x] = 0;
+    __syncthreads();
     n_assigned = wave_sum(n_assigned);
     n_lowq = wave_sum(n_lowq);
     n_bad = wave_sum(n_bad);
     n_qc = wave_sum(n_qc);
     n_enh = wave_sum(n_enh);
     if ((threadIdx.x & 63) == 0) {
-        if (n_assigned) atomicAdd(&stats[1], (unsigned long long)n_assigned);
-        if (n_lowq) atomicAdd(&stats[2], (unsigned long long)n_lowq);
-        if (n_bad) atomicAdd(&stats[3], (unsigned long long)n_bad);
-        if (n_qc) atomicAdd(&stats[4], (unsigned long long)n_qc);
-        if (n_enh) atomicAdd(&stats[5], (unsigned long long)n_enh);
+        if (n_assigned) atomicAdd(&tally[0], n_assigned);
+        if (n_lowq) atomicAdd(&tally[1], n_lowq);
+        if (n_bad) atomicAdd(&tally[2], n_bad);
+        if (n_qc) atomicAdd(&tally[3], n_qc);
+        if (n_enh) atomicAdd(&tally[4], n_enh);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 5 && tally[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -935,11 +942,18 @@ __global__ __launch_bounds__(kBlock) void part_pass_kernel(tec_index_dev idx, co
         __syncthreads();
         for (uint32_t w = threadIdx.x; w < W; w += kBlock) H[(size_t)w * G + blockIdx.x] = cur[w];
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+        // cur[] has been copied out: its first words carry the workgroup's tallies to one thread
+        __syncthreads();
+        if (threadIdx.x < 3) cur[threadIdx.x] = 0;
+        __syncthreads();
         if ((threadIdx.x & 63) == 0) {
-            if (w_lowq) atomicAdd(&stats[2], (unsigned long long)w_lowq);
-            if (w_bad) atomicAdd(&stats[3], (unsigned long long)w_bad);
-            if (w_qc) atomicAdd(&stats[4], (unsigned long long)w_qc);
+            if (w_lowq) atomicAdd(&cur[0], w_lowq);
+            if (w_bad) atomicAdd(&cur[1], w_bad);
+            if (w_qc) atomicAdd(&cur[2], w_qc);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x < 3 && cur[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], (unsigned long long)cur[threadIdx.x]);
     }
 }
 

@@ -132,11 +132,6 @@ __device__ __forceinline__ int wl_find(const uint64_t* __restrict__ wl, const ui
     }
 }
 
-__device__ __forceinline__ void wave_add(unsigned long long* ctr, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
-}
-
 // Tallies of a whole block: waves add into LDS, one thread per counter adds to global memory.
 // (One global atomic per WAVE on the few adjacent stat counters -- millions of memory-side atomics
 // on one 64-byte line, ~7 ns each -- was a third of the ingest time of a 50 M-record run.)
@@ -354,6 +349,9 @@ __global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_
                             const uint32_t* __restrict__ selprefix, const uint32_t* __restrict__ gid, uint8_t* kept_rec,
                             uint32_t* firstkept, unsigned long long* n_kept) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t tally_lds[1];
+    BlockTally<1> tally{tally_lds};
+    tally.begin();
     bool k = false;
     if (j < n_lines) {
         const uint32_t i = line_rec[j];
@@ -364,7 +362,9 @@ __global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_
         kept_rec[i] = k;
         if (k) atomicMin(&firstkept[gid[i]], i);
     }
-    wave_add(n_kept, k);
+    tally.add(0, k);
+    unsigned long long* const dst[1] = {n_kept};
+    tally.end(dst);
 }
 
 // A record feeds part 3 iff its instance survived part 2 and it is the head, or an extra string
