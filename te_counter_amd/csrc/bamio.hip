@@ -456,7 +456,14 @@ extern "C" int tec_bam_open(const char* path, int n_threads, tec_bam** out) {
     if (!fh) return bam_fail(nullptr, TEC_EINVAL, std::string("cannot open ") + path);
     tec_bam* r = new tec_bam();
     r->fh = fh;
-    r->n_threads = n_threads > 0 ? n_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    // n_threads <= 0: TEC_BAM_THREADS if set, else min(16, cores) (16 is one GPU's share of a host's cores)
+    {
+        const char* e = getenv("TEC_BAM_THREADS");
+        const int env_threads = e ? atoi(e) : 0;
+        r->n_threads = n_threads > 0 ? n_threads
+                       : env_threads > 0 ? std::min(env_threads, 256)
+                                         : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    }
     uint8_t m[4] = {0};
     const size_t got = fread(m, 1, 4, fh);
     fseek(fh, 0, SEEK_SET);
