@@ -6,7 +6,7 @@ import pytest
 
 from oracle import c_oracle
 from oracle import te_oracle as orc
-from te_counter_amd import Engine, FlatIndex, measureTE
+from te_counter_amd import Engine, FlatIndex, _lib, measureTE
 from te_counter_amd.reads import ListSource
 
 pytestmark = pytest.mark.gpu
@@ -129,3 +129,50 @@ def test_many_chromosomes():
     got, gst = eng.bulk_finish()
     assert np.array_equal(got, want) and all(gst[k] == v for k, v in wst.items())
     eng.close()
+
+
+@pytest.mark.parametrize('mixed', [False, True])
+@pytest.mark.parametrize('paired', [True, False])
+def test_dense_pileups_long_lists_and_many_names(mixed, paired):
+    """Fine bins with dozens of entries (continuation pieces AND the walk beyond them), units that
+    hit more than six distinct names (exact walk), edges on and next to 10 kb boundaries, in every
+    record-kernel variant; against the C oracle."""
+    rng = np.random.default_rng(29 + mixed + 2 * paired)
+    n_names = 90
+    feats = []
+    # pile-ups: around a few centres, 40-120 features of many names overlapping within ~1.5 kb
+    centres = [9_000, 10_000, 19_990, 20_000, 30_010, 55_555, 99_999, 100_000, 250_000]
+    for c in centres:
+        for _ in range(int(rng.integers(40, 120))):
+            left = int(c + rng.integers(-900, 900))
+            right = left + int(rng.integers(1, 700))
+            feats.append((0, max(0, left), right, int(rng.integers(0, n_names))))
+    # a sparse background on two chromosomes
+    for _ in range(3000):
+        left = int(rng.integers(0, 400_000))
+        feats.append((int(rng.integers(0, 2)), left, left + int(rng.integers(1, 3000)), int(rng.integers(0, n_names))))
+    classes = [_lib.CLASS_GENE, _lib.CLASS_TE, _lib.CLASS_SNRNA] + ([_lib.CLASS_OTHER] if mixed else [])
+    name_class = rng.integers(0, len(classes), n_names)
+    chrom = np.array([f[0] for f in feats], np.int32)
+    left = np.array([f[1] for f in feats], np.int32)
+    right = np.array([f[2] for f in feats], np.int32)
+    meta = np.array([f[3] | (classes[name_class[f[3]]] << _lib.META_CLASS_SHIFT) for f in feats], np.uint32)
+    flat = FlatIndex(['N%03d' % i for i in range(n_names)], ['1', '2'], ['+', '-'], chrom, left, right, meta)
+    n = 400_000
+    c = rng.choice(centres, n)
+    p1 = (c + rng.integers(-1200, 1200, n)).astype(np.int32)
+    p1[::7] = (rng.integers(0, 40, len(p1[::7])) * 10_000 + rng.integers(-2, 3, len(p1[::7]))).astype(np.int32)
+    p2 = (p1 + (rng.integers(-400, 400, n) if paired else rng.integers(1, 2500, n))).astype(np.int32)
+    p2[::11] = (rng.integers(1, 40, len(p2[::11])) * 10_000 - 1 + rng.integers(-2, 3, len(p2[::11]))).astype(np.int32)
+    units = (rng.integers(0, 2, n).astype(np.int32), p1, p2, np.zeros(n, np.uint16), np.full(n, 255, np.uint8))
+    want, wst = c_oracle.COracleIndex.from_flat(flat).bulk_count(*units, 20)
+    assert want.max() > 0
+    for shift in (0, 7, 9, 12):
+        eng = Engine(0)
+        eng.upload_index(flat, shift)
+        eng.bulk_begin(20)
+        eng.bulk_submit(*units)
+        got, gst = eng.bulk_finish()
+        eng.close()
+        assert np.array_equal(got, want), (shift, int(np.abs(got.astype(np.int64) - want.astype(np.int64)).sum()))
+        assert all(gst[k] == v for k, v in wst.items())
