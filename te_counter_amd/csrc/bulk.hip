@@ -253,21 +253,31 @@ __device__ __forceinline__ void store_hist(const uint32_t* hist, uint32_t words4
 }
 
 // counts[2w] += sum over rows of the low halves of word w, counts[2w+1] += the high halves.
+// The rows of up to kSlabSlots launches are folded at once (one reduce per kSlabSlots launches, or at
+// the next sync): slot s holds used.n[s] rows of `stride` words at slabs + s * slot_rows * stride.
 // blockIdx.y strides over the rows so that enough loads are in flight.
+constexpr int kSlabSlots = 8;
+struct SlabRows {
+    uint32_t n[kSlabSlots];
+};
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const uint32_t* __restrict__ slabs, uint32_t stride,
-                                                           uint32_t words, uint32_t rows,
-                                                           unsigned long long* counts) {
+                                                           uint32_t words, SlabRows used, uint32_t n_slots,
+                                                           uint32_t slot_rows, unsigned long long* counts) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= words) return;
-    uint32_t lo = 0, hi = 0;  // <= 65 535 per row, a few hundred rows
+    unsigned long long lo = 0, hi = 0;  // <= 65 535 per row
+    for (uint32_t s = 0; s < n_slots; ++s) {
+        const uint32_t* __restrict__ base = slabs + (size_t)s * slot_rows * stride;
+        const uint32_t rows = used.n[s];
 #pragma unroll 8
-    for (uint32_t g = blockIdx.y; g < rows; g += gridDim.y) {
-        const uint32_t v = slabs[(size_t)g * stride + w];
-        lo += v & 0xFFFFu;
-        hi += v >> 16;
+        for (uint32_t g = blockIdx.y; g < rows; g += gridDim.y) {
+            const uint32_t v = base[(size_t)g * stride + w];
+            lo += v & 0xFFFFu;
+            hi += v >> 16;
+        }
     }
-    if (lo) atomicAdd(&counts[2u * w], (unsigned long long)lo);
-    if (hi) atomicAdd(&counts[2u * w + 1u], (unsigned long long)hi);
+    if (lo) atomicAdd(&counts[2u * w], lo);
+    if (hi) atomicAdd(&counts[2u * w + 1u], hi);
 }
 
 // MIXED = the index holds classes that are not countable in bulk (miRNA..., enhancer): the class
@@ -1095,10 +1105,41 @@ int harvest_timers(tec_ctx* ctx) {
         float ms = 0.f;
         TEC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].start, ctx->ev_pool[i].stop));
         ctx->kernel_ms += ms;
-        TEC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].stop, ctx->ev_pool[i].reduced));
-        ctx->reduce_ms += ms;
     }
     ctx->ev_used = 0;
+    for (size_t i = 0; i < ctx->red_used; ++i) {
+        float ms = 0.f;
+        TEC_HIP(ctx, hipEventElapsedTime(&ms, ctx->red_pool[i].start, ctx->red_pool[i].stop));
+        ctx->reduce_ms += ms;
+    }
+    ctx->red_used = 0;
+    return TEC_OK;
+}
+
+// Folds the histogram rows of the launches since the last reduce into the count vector.
+int flush_slabs(tec_ctx* ctx) {
+    if (ctx->slab_slot == 0) return TEC_OK;
+    if (ctx->red_used == ctx->red_pool.size()) {
+        tec_event_pair p;
+        TEC_HIP(ctx, hipEventCreate(&p.start));
+        TEC_HIP(ctx, hipEventCreate(&p.stop));
+        p.reduced = nullptr;
+        ctx->red_pool.push_back(p);
+    }
+    tec_event_pair& ev = ctx->red_pool[ctx->red_used++];
+    SlabRows used{};
+    uint32_t total_rows = 0;
+    for (int k = 0; k < ctx->slab_slot; ++k) {
+        used.n[k] = ctx->slab_used[k];
+        total_rows += ctx->slab_used[k];
+    }
+    const uint32_t words = ctx->slab_words;
+    const unsigned split = std::max(1u, std::min(total_rows / 64u, 32u));
+    hipExtLaunchKernelGGL(reduce_slabs_kernel, dim3((words + 255u) / 256u, split), dim3(256), 0u, ctx->s_compute, ev.start,
+                          ev.stop, 0u, (const uint32_t*)ctx->d_slabs, words, words, used, (uint32_t)ctx->slab_slot,
+                          (uint32_t)ctx->n_cu, ctx->d_counts);
+    TEC_HIP(ctx, hipGetLastError());
+    ctx->slab_slot = 0;
     return TEC_OK;
 }
 
@@ -1113,11 +1154,13 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
             tec_event_pair p;
             TEC_HIP(ctx, hipEventCreate(&p.start));
             TEC_HIP(ctx, hipEventCreate(&p.stop));
-            TEC_HIP(ctx, hipEventCreate(&p.reduced));
+            p.reduced = nullptr;
             ctx->ev_pool.push_back(p);
         }
     }
-    tec_event_pair& ev = ctx->ev_pool[ctx->ev_used++];
+    const bool timed = ctx->partition || ctx->time_every == 1 || (ctx->time_every > 1 && ctx->kernel_launches % (uint64_t)ctx->time_every == 0);
+    tec_event_pair& ev = ctx->ev_pool[timed ? ctx->ev_used++ : ctx->ev_used];
+    if (timed) ++ctx->timed_launches;
     const int unroll = ctx->unroll;
     const uint64_t chunk = (uint64_t)unroll * kBlock;
     const uint64_t want = (n + chunk - 1) / chunk;
@@ -1131,8 +1174,15 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const size_t lds = (size_t)words * 4;
     const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu);
     // one histogram row per workgroup; reduce_slabs_kernel folds them into the count vector
-    const size_t slab_bytes = (size_t)ctx->n_cu * words * sizeof(uint32_t);
+    if (ctx->slab_slot && ctx->slab_words != words) {  // the histogram width changed: fold what is pending first
+        int rc = flush_slabs(ctx);
+        if (rc) return rc;
+    }
+    ctx->slab_words = words;
+    const size_t slab_bytes = (size_t)kSlabSlots * ctx->n_cu * words * sizeof(uint32_t);
     if (slab_bytes > ctx->slab_cap) {
+        int rc = flush_slabs(ctx);
+        if (rc) return rc;
         TEC_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
         if (ctx->d_slabs) TEC_HIP(ctx, hipFree(ctx->d_slabs));
         ctx->d_slabs = nullptr;
@@ -1144,7 +1194,8 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
     if (span < chunk) span = chunk;
     const bool rec_ok = ctx->kernel_variant == 2 && ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3;
-    unsigned rows = grid;  // histogram rows the reduce kernel folds
+    unsigned rows = grid;  // histogram rows of this launch
+    uint32_t* const slab = ctx->d_slabs + (size_t)ctx->slab_slot * ctx->n_cu * words;
     if (ctx->partition && rec_ok && unroll == 2 && (n >= (1u << 16) || ctx->partition == 2) && n < 0xFFFF0000ull) {
         TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
         // ---- partitioned pipeline: histogram, scan, scatter, count over the items
@@ -1201,23 +1252,23 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
                            ctx->idx, reinterpret_cast<const int32_t*>(items), reinterpret_cast<const int32_t*>(pm),
                            (const int32_t*)nullptr, (const uint16_t*)nullptr, (const uint8_t*)nullptr, (uint64_t)0,
                            ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, (uint64_t)1, (uint32_t)ctx->aggregate,
-                           ctx->d_slabs);
+                           slab);
         TEC_HIP(ctx, hipGetLastError());
         TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
     } else {
         // start / stop timestamps ride on the dispatch itself: no barrier packets between the launches
         hipExtLaunchKernelGGL(pick_kernel(mixed, unroll, rec_ok ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid),
-                              dim3(kBlock), (uint32_t)lds, ctx->s_compute, ev.start, ev.stop, 0u, ctx->idx, u.chrom, u.p1, u.p2,
+                              dim3(kBlock), (uint32_t)lds, ctx->s_compute, timed ? ev.start : (hipEvent_t) nullptr,
+                              timed ? ev.stop : (hipEvent_t) nullptr, 0u, ctx->idx, u.chrom, u.p1, u.p2,
                               u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                              (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, ctx->d_slabs);
+                              (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, slab);
         TEC_HIP(ctx, hipGetLastError());
     }
-    {
-        const unsigned split = std::max(1u, std::min(rows / 16u, 32u));  // >= 16 rows per thread
-        hipExtLaunchKernelGGL(reduce_slabs_kernel, dim3((words + 255u) / 256u, split), dim3(256), 0u, ctx->s_compute,
-                              (hipEvent_t) nullptr, ev.reduced, 0u, (const uint32_t*)ctx->d_slabs, words, words, rows,
-                              ctx->d_counts);
-        TEC_HIP(ctx, hipGetLastError());
+    // the rows wait in their slot; one reduce folds kSlabSlots launches (or what is pending at the next sync)
+    ctx->slab_used[ctx->slab_slot++] = rows;
+    if (ctx->slab_slot == kSlabSlots) {
+        int rc = flush_slabs(ctx);
+        if (rc) return rc;
     }
     ++ctx->kernel_launches;
     return TEC_OK;
@@ -1257,6 +1308,8 @@ int tec_bulk_init(tec_ctx* ctx) {
 #endif
     e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup
     ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 154 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
+    e = getenv("TEC_TIME_EVERY");  // experiment: timestamp only every k-th count launch (0 = never)
+    ctx->time_every = e ? atoi(e) : 1;
     e = getenv("TEC_PARTITION");  // 1: group the live units by genome window before counting (shuffled batches)
     ctx->partition = e ? atoi(e) : 0;  // 2: also for tiny batches (tests)
     e = getenv("TEC_PART_WSHIFT");  // tuning knob: log2(fine bins per window), 0 = automatic
@@ -1276,10 +1329,16 @@ int tec_bulk_release(tec_ctx* ctx) {
     for (auto& p : ctx->ev_pool) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
-        (void)hipEventDestroy(p.reduced);
     }
     ctx->ev_pool.clear();
     ctx->ev_used = 0;
+    for (auto& p : ctx->red_pool) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    ctx->red_pool.clear();
+    ctx->red_used = 0;
+    ctx->slab_slot = 0;
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     ctx->d_slabs = nullptr;
     ctx->slab_cap = 0;
@@ -1300,9 +1359,11 @@ extern "C" int tec_bulk_begin(tec_ctx* ctx, int mapq_min) {
     int rc = harvest_timers(ctx);
     if (rc) return rc;
     ctx->mapq_min = mapq_min;
+    ctx->slab_slot = 0;
     ctx->kernel_ms = 0.0;
     ctx->reduce_ms = 0.0;
     ctx->kernel_launches = 0;
+    ctx->timed_launches = 0;
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)ctx->idx.n_names + 2) * sizeof(unsigned long long), ctx->s_compute));
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), ctx->s_compute));
     ctx->bulk_open = true;
@@ -1378,6 +1439,12 @@ extern "C" int tec_bulk_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* c
 extern "C" int tec_bulk_sync(tec_ctx* ctx) {
     if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_sync: NULL context");
     TEC_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        // the last launches' histogram rows may still wait for their reduce (it must follow the
+        // copy stream's batches too: they were launched on s_compute behind their copy events)
+        int rc = flush_slabs(ctx);
+        if (rc) return rc;
+    }
     TEC_HIP(ctx, hipStreamSynchronize(ctx->s_copy));
     TEC_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
     return harvest_timers(ctx);
@@ -1435,7 +1502,7 @@ extern "C" int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* la
     int rc = tec_bulk_sync(ctx);
     if (rc) return rc;
     if (total_ms) *total_ms = ctx->kernel_ms;
-    if (launches) *launches = ctx->kernel_launches;
+    if (launches) *launches = ctx->timed_launches;  // the launches that carried timestamps (all of them by default)
     return TEC_OK;
 }
 

@@ -37,7 +37,7 @@ struct tec_index_dev {
 };
 
 struct tec_event_pair {
-    hipEvent_t start, stop, reduced;  // count kernel between start and stop, slab reduce up to `reduced`
+    hipEvent_t start, stop, reduced;  // a kernel between start and stop (`reduced` unused)
 };
 
 struct tec_slot {  // one staged batch in HBM
@@ -80,12 +80,18 @@ struct tec_ctx {
     double kernel_ms = 0.0, reduce_ms = 0.0;
     uint32_t* d_slabs = nullptr;  // [workgroups x histogram words] per-workgroup histogram rows of a launch
     size_t slab_cap = 0;
+    int time_every = 1;
+    int slab_slot = 0;              // launches whose rows wait for the next reduce
+    uint32_t slab_used[8] = {0};    // rows written by each of them
+    uint32_t slab_words = 0;
+    std::vector<tec_event_pair> red_pool;  // start / stop of the reduce kernels
+    size_t red_used = 0;
     // partitioned pipeline (bulk.hip): items grouped by genome window, window x workgroup offsets, chunk lists
     int partition = 0;
     int part_wshift = 0;
     void *d_part_items = nullptr, *d_part_h = nullptr, *d_part_pm = nullptr;
     size_t part_items_cap = 0, part_h_cap = 0, part_pm_cap = 0;
-    uint64_t kernel_launches = 0;
+    uint64_t kernel_launches = 0, timed_launches = 0;
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
     int aggregate = 0;
