@@ -539,7 +539,7 @@ bool extract_record(const uint8_t* rec, uint64_t w, const OutArrays& a) {
     return true;
 }
 
-// One chunk: up to 512 BGZF blocks in contiguous shares, one per thread.  A thread inflates its
+// One chunk: 512 or more BGZF blocks (at least 32 per thread, so that a share stays cache-sized) in contiguous shares, one per thread.  A thread inflates its
 // share, then -- holding the baton {next record start, records so far} from the thread before it --
 // walks the record boundaries of its share while the bytes are still in its cache, hands the baton
 // on, and extracts the fields of its own records.  Only the boundary walk is sequential, and it
@@ -553,7 +553,9 @@ int read_chunk(tec_bam* r, uint64_t max_left, uint64_t first_row, const OutArray
     }
     std::vector<RawBlock> blocks;
     size_t total = 0;
-    const int k = discover_blocks(r, 512, &blocks, &total);
+    // chunk size grows with the thread count: the per-chunk costs (thread start, the baton chain,
+    // block discovery) are sequential
+    const int k = discover_blocks(r, std::max<size_t>(512, 32 * (size_t)r->n_threads), &blocks, &total);
     if (k < 0) return k;
     if (k == 0) return TEC_OK;
     const size_t base = r->buf.size();
