@@ -42,9 +42,11 @@ template <class T>
 struct dvec {
     T* p = nullptr;
     size_t cap = 0;
-    hipError_t reserve(size_t n, bool keep = false, size_t used = 0) {
+    // floor: a capacity hint for buffers that will keep growing (the survivor arrays): every
+    // regrowth is a hipMalloc (cleared by the driver), a device copy and a hipFree
+    hipError_t reserve(size_t n, bool keep = false, size_t used = 0, size_t floor = 0) {
         if (n <= cap) return hipSuccess;
-        size_t want = std::max(n, cap + cap / 2);
+        size_t want = std::max(std::max(n, floor), keep ? cap * 2 : cap + cap / 2);
         T* q = nullptr;
         hipError_t e = hipMalloc(&q, std::max<size_t>(want, 1) * sizeof(T));
         if (e != hipSuccess) return e;
@@ -682,14 +684,16 @@ extern "C" int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const
     const uint64_t add = (uint64_t)last_scan + last_live;
     const uint64_t need = s->n_live + add;
     if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
-    SC_HIP(s->bcid.reserve(need, true, s->n_live));
-    SC_HIP(s->u0.reserve(need, true, s->n_live));
-    SC_HIP(s->u1.reserve(need, true, s->n_live));
-    SC_HIP(s->u2.reserve(need, true, s->n_live));
-    SC_HIP(s->rec.reserve(need, true, s->n_live));
-    SC_HIP(s->klass.reserve(need, true, s->n_live));
-    SC_HIP(s->left.reserve(need, true, s->n_live));
-    SC_HIP(s->rite.reserve(need, true, s->n_live));
+    // survivor arrays: room for sixteen batches like this one (<= 128 M records) at the first allocation, doubling after that
+    const size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);  // at most 6 GB up front
+    SC_HIP(s->bcid.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->u0.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->u1.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->u2.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->rec.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->klass.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->left.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->rite.reserve(need, true, s->n_live, floor));
     hipLaunchKernelGGL(sc_scatter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, s->n_live, s->b_live.p,
                        s->b_scan.p, s->b_bcid.p, (const int32_t*)(b + o_cls), (const int32_t*)(b + o_pos),
                        (const int32_t*)(b + o_end), (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_ub), s->stranded,
