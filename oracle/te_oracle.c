@@ -9,7 +9,7 @@
  *     (te_count/te_count.py:201-263 / 76-152) on pre-decoded units.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  * Parity status: pinned -- checked against the golden vectors captured from the reference
- * (tests/test_oracle_golden.py::test_c_oracle_*), and against oracle/te_oracle.py.
+ * (tests/test_host_cpu.py::test_c_oracle_golden), and against oracle/te_oracle.py.
  */
 #include <stdint.h>
 #include <stdlib.h>

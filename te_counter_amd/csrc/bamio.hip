@@ -172,6 +172,7 @@ int discover_blocks(tec_bam* r, size_t max_blocks, std::vector<RawBlock>* blocks
         b.off = r->raw_pos + 12 + xlen;
         b.clen = (size_t)clen;
         b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (b.isize > 65536u) return bam_fail(r, TEC_EINVAL, "corrupt BGZF block (ISIZE above 64 KiB)");  // SAMv1 4.1
         b.out_off = *total;
         *total += b.isize;
         r->raw_pos += (size_t)bsize + 1;
@@ -195,8 +196,10 @@ int refill(tec_bam* r, size_t max_blocks) {
     if (!r->buf.grow(total)) return bam_fail(r, TEC_EINVAL, "out of memory for the inflate window");
     std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
     for (const RawBlock& b : blocks)
-        if (b.isize && !inflate_one(raw_base(r) + b.off, b.clen, r->buf.data() + base + b.out_off, b.isize, tabs.get()))
+        if (b.isize && !inflate_one(raw_base(r) + b.off, b.clen, r->buf.data() + base + b.out_off, b.isize, tabs.get())) {
+            r->buf.n = base;  // the window holds nothing of this refill
             return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
+        }
     return 1;
 }
 
@@ -397,7 +400,9 @@ int sam_record(tec_bam* r, uint64_t o, const OutArrays& a) {
     }
     a.tid[o] = tid;
     a.pos[o] = (int32_t)(pos1 - 1);
-    a.end[o] = have_cigar ? (int32_t)(pos1 - 1 + reflen) : INT32_MIN;  // pysam: reference_end is None
+    // pysam: reference_end is None without a CIGAR; htslib's bam_endpos counts a CIGAR that
+    // consumes no reference base (only S/I/H/P) as one base
+    a.end[o] = have_cigar ? (int32_t)(pos1 - 1 + (reflen ? reflen : 1)) : INT32_MIN;
     a.flag[o] = (uint16_t)strtoul(s.c_str() + f[1].first, nullptr, 10);
     a.mapq[o] = (uint8_t)strtoul(s.c_str() + f[4].first, nullptr, 10);
     if (a.qkey) a.qkey[o] = mate_key_hash(s.c_str() + f[0].first, f[0].second);
@@ -525,7 +530,9 @@ bool extract_record(const uint8_t* rec, uint64_t w, const OutArrays& a) {
     }
     a.tid[w] = refid;
     a.pos[w] = p0;
-    a.end[w] = n_cig ? (int32_t)(p0 + reflen) : INT32_MIN;  // pysam: reference_end is None without a CIGAR
+    // pysam: reference_end is None without a CIGAR; htslib's bam_endpos counts a CIGAR that consumes
+    // no reference base (only S/I/H/P) as one base
+    a.end[w] = n_cig ? (int32_t)(p0 + (reflen ? reflen : 1)) : INT32_MIN;
     a.flag[w] = le16(p + 14);
     a.mapq[w] = p[9];
     if (a.qkey) a.qkey[w] = mate_key_hash((const char*)name, l_name ? l_name - 1 : 0);
@@ -632,6 +639,8 @@ int read_chunk(tec_bam* r, uint64_t max_left, uint64_t first_row, const OutArray
         for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
         for (auto& x : th) x.join();
     }
+    for (int t = 0; t < nt; ++t)
+        if (status[t]) r->buf.n = base;  // a failed chunk leaves nothing in the window
     for (int t = 0; t < nt; ++t) {
         if (status[t] == 1) return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
         if (status[t] == 2) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");

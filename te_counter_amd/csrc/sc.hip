@@ -398,7 +398,10 @@ struct ScQuery {
 __device__ __forceinline__ bool sc_t1(const tec_entry& e, const ScQuery& q) { return (long long)q.left + 1 >= e.left && q.left <= e.right; }
 __device__ __forceinline__ bool sc_t2(const tec_entry& e, const ScQuery& q) { return q.rite >= e.left && (long long)q.rite - 1 <= e.right; }
 __device__ __forceinline__ bool sc_cand(const tec_entry& e, const ScQuery& q) {
-    return q.bhi >= q.blo && bucket_of(e.left) <= q.bhi && bucket_of(e.right) >= q.blo;
+    // a degenerate feature with floor(left/bs) > floor(right/bs) (right == left - 1 across a 10 kb
+    // boundary) is filed under no bucket at all (genelist.py:371-373: empty range)
+    const int lo = bucket_of(e.left), hi = bucket_of(e.right);
+    return q.bhi >= q.blo && lo <= hi && lo <= q.bhi && hi >= q.blo;
 }
 __device__ __forceinline__ int floor_bucket(long long x) {
     long long b = x / TEC_BUCKET_SIZE;

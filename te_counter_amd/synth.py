@@ -262,6 +262,31 @@ def make_sc_arrays(ann, n_records, n_cells=10000, n_whitelist=737280, seed=2004,
     return arrays, wl, (names, class_chrom, class_skip)
 
 
+def features_overlapping(flat, chrom, lo, hi):
+    """Feature dicts (oracle schema) of every index row that overlaps one of the windows
+    [lo[i], hi[i]] on chromosome id chrom[i] (negative ids are skipped): lets the Python oracle check a
+    sample of records against a multi-million-row annotation without materialising all of it."""
+    order = np.argsort((flat.chrom_id.astype(np.int64) << 32) + flat.left, kind='stable')
+    starts = ((flat.chrom_id.astype(np.int64) << 32) + flat.left)[order]
+    rights = flat.right[order].astype(np.int64)
+    maxlen = int((flat.right.astype(np.int64) - flat.left).max()) + 1
+    chrom = np.asarray(chrom, np.int64)
+    lo, hi = np.asarray(lo, np.int64), np.asarray(hi, np.int64)
+    ok = chrom >= 0
+    a = np.searchsorted(starts, (chrom << 32) + np.maximum(0, lo - maxlen))
+    b = np.searchsorted(starts, (chrom << 32) + hi, 'right')
+    near = np.zeros(len(flat), bool)
+    for i in np.nonzero(ok)[0].tolist():
+        sl = slice(a[i], b[i])
+        near[order[sl][rights[sl] >= lo[i]]] = True
+    sel = np.nonzero(near)[0]
+    strands = flat.strands
+    return [{'chr': flat.chrom_keys[c], 'left': int(l), 'right': int(r), 'strand': strands[(m >> 29) & 7], 'name': 'x',
+             'type': 'TE' if ((m >> 26) & 7) == 2 else 'protein_coding', 'ensg': flat.names[m & ((1 << 26) - 1)]}
+            for c, l, r, m in zip(flat.chrom_id[sel].tolist(), flat.left[sel].tolist(), flat.right[sel].tolist(),
+                                  flat.meta[sel].tolist())]
+
+
 def sc_arrays_to_records(arrays, names):
     """The same records as dicts (oracle / reference schema) -- small inputs only."""
     recs = []

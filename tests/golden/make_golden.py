@@ -143,6 +143,20 @@ def main():
     recs = dg.make_sc_records(323, 9000, wl, feats, n_cells=1400, reads_per_umi=1.2)
     sc_case('sc_topcells_binding', feats, recs, wl, 3, False)
     sc_case('sc_topcells_binding_multibundle', feats, recs, wl, 3, True, thr=1000)
+    # a degenerate feature (right == left - 1) astride a 10 kb boundary is filed under no bucket
+    # (genelist.py:371-373) although it passes the single-cell window test; inside a bucket it counts
+    dfeats = [{'chr': 'chr1', 'left': 10000, 'right': 9999, 'strand': '+', 'name': 'a', 'type': 'protein_coding', 'ensg': 'STRADDLE'},
+              {'chr': 'chr1', 'left': 10005, 'right': 10004, 'strand': '+', 'name': 'b', 'type': 'protein_coding', 'ensg': 'INSIDE'},
+              {'chr': 'chr1', 'left': 20000, 'right': 19999, 'strand': '-', 'name': 'c', 'type': 'TE', 'ensg': 'LINE:L1:s'},
+              {'chr': 'chr1', 'left': 500, 'right': 900, 'strand': '+', 'name': 'd', 'type': 'protein_coding', 'ensg': 'PLAIN'}]
+    dwl = ['AAAA', 'CCCC']
+    drecs = []
+    for k, (pos, end) in enumerate([(9999, 10050), (9950, 10000), (10004, 10100), (9990, 10005), (19999, 20050),
+                                    (19900, 20000), (600, 700), (9998, 9999), (10000, 10001)] * 3):
+        drecs.append({'flag': 0, 'mapq': 255, 'rname': 'chr1', 'pos': pos, 'end': end,
+                      'tags': {'CB': dwl[k % 2], 'UB': 'ACGT'[k % 4] + 'ACGT'[(k // 4) % 4] + 'ACGT'[(k // 16) % 4]}})
+    sc_case('sc_degenerate_boundary', dfeats, drecs, dwl, 10, False)
+    sc_case('sc_degenerate_boundary_strand', dfeats, drecs, dwl, 10, True)
     # sc failure modes
     wl = dg.make_whitelist(24, 20)
     recs = dg.make_sc_records(324, 200, wl, None, n_cells=4)

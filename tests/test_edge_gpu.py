@@ -93,6 +93,26 @@ def test_sc_odd_barcodes_and_umis(tmp_path):
         _sc(feats, recs, wl, tmp_path, strand=strand, thr=7)
 
 
+def test_sc_degenerate_feature_across_a_bucket_boundary(tmp_path):
+    """A feature with right == left - 1 passes the single-cell 2-bp window test for a read starting
+    at left - 1, but when it straddles a 10 kb boundary (left = 10000, right = 9999) the reference
+    files it under no bucket at all (genelist.py:371-373) and never looks at it; the same feature
+    inside one bucket (left = 10005, right = 10004) is counted."""
+    feats = [{'chr': 'chr1', 'left': 10000, 'right': 9999, 'strand': '+', 'name': 'a', 'type': 'protein_coding', 'ensg': 'STRADDLE'},
+             {'chr': 'chr1', 'left': 10005, 'right': 10004, 'strand': '+', 'name': 'b', 'type': 'protein_coding', 'ensg': 'INSIDE'},
+             {'chr': 'chr1', 'left': 20000, 'right': 19999, 'strand': '-', 'name': 'c', 'type': 'TE', 'ensg': 'LINE:L1:s'},
+             {'chr': 'chr1', 'left': 500, 'right': 900, 'strand': '+', 'name': 'd', 'type': 'protein_coding', 'ensg': 'PLAIN'}]
+    wl = ['AAAA', 'CCCC']
+    recs = []
+    for k, (pos, end) in enumerate([(9999, 10050), (9950, 10000), (10004, 10100), (9990, 10005), (19999, 20050),
+                                    (19900, 20000), (600, 700), (9998, 9999), (10000, 10001)] * 3):
+        recs.append({'flag': 0, 'mapq': 255, 'rname': 'chr1', 'pos': pos, 'end': end,
+                     'tags': {'CB': wl[k % 2], 'UB': 'ACGT'[k % 4] + 'ACGT'[(k // 4) % 4] + 'ACGT'[(k // 16) % 4]}})
+    m = _sc(feats, recs, wl, tmp_path)
+    assert 'INSIDE' in {k for k, v in orc.sc_count(feats, recs, wl, 10)[0].items() if v}
+    assert m is not None
+
+
 def test_sc_everything_filtered_raises_like_the_reference(tmp_path):
     feats = [{'chr': 'chr1', 'left': 100, 'right': 500, 'strand': '+', 'name': 'g', 'type': 'protein_coding', 'ensg': 'G1'}]
     recs = [{'flag': 0x4, 'mapq': 255, 'rname': 'chr1', 'pos': 150, 'end': 250, 'tags': {'CB': 'AAAA', 'UB': 'CC'}},

@@ -20,6 +20,15 @@ def hg38():
     eng.close()
 
 
+@pytest.fixture(scope='module')
+def mm10():
+    ann = synth.make_annotation('mm10')
+    eng = Engine(0)
+    eng.upload_index(ann.flat)
+    yield ann, eng
+    eng.close()
+
+
 def _count(eng, units, parts=1, q=20):
     eng.bulk_begin(q)
     n = len(units[0])
@@ -29,10 +38,13 @@ def _count(eng, units, parts=1, q=20):
     return eng.bulk_finish()
 
 
-@pytest.mark.parametrize('paired,n_units', [(True, 62_500_000), (False, 100_000_000)])
-def test_full_size_properties(hg38, paired, n_units):
-    """Headline shape (125 M PE records) and BASELINE config 2 (100 M SE records, -q 20)."""
-    ann, eng = hg38
+@pytest.mark.parametrize('genome,paired,n_units', [('hg38', True, 62_500_000), ('hg38', False, 100_000_000),
+                                                   ('mm10', True, 62_500_000)])
+def test_full_size_properties(request, genome, paired, n_units):
+    """Headline shape (125 M PE records), BASELINE config 2 (100 M SE records, -q 20) and BASELINE
+    config 3 (mm10 genes_tes, PE, one GPU's share of the 500 M records = 62.5 M pair units; counted
+    without --strand because the reference refuses bulk --strand, te_count.py:58-59)."""
+    ann, eng = request.getfixturevalue(genome)
     units = synth.make_units(ann, n_units, seed=2002 if not paired else 2003, paired=paired)
     full, st = _count(eng, units, parts=4)
     assert st['units'] == n_units
@@ -66,6 +78,86 @@ def test_full_size_properties(hg38, paired, n_units):
         eng.bulk_submit(*units)
     twice, tst = eng.bulk_finish()
     assert np.array_equal(twice, 2 * full) and tst['assigned'] == 2 * st['assigned']
+
+
+def test_config1_mm10_pe_2M_records_full_oracle_and_cli(mm10, tmp_path):
+    """BASELINE config 1 (test/data/bulk_rnaseq_PE.bam is a missing blob: 2 M synthetic PE records
+    against the mm10-like genes_tes annotation).  Every count is compared with the C
+    oracle, and the same records go BAM file -> bin/te_count's code path -> TSV, whose bytes must be
+    what the reference's writer (te_count.py:279-296, restated in the oracle) gives for those counts."""
+    from oracle import te_oracle as orc
+    from te_counter_amd import bam, cli
+    ann, eng = mm10
+    n_units = 1_000_000
+    units = synth.make_units(ann, n_units, seed=2001, paired=True)
+    ci = c_oracle.COracleIndex.from_flat(ann.flat)
+    want, wst = ci.bulk_count(*units, 20)
+    got, gst = _count(eng, units, parts=3)
+    assert np.array_equal(got, want) and all(gst[k] == v for k, v in wst.items())
+    assert int(want.sum()) > 300_000
+    # the same pairs as a BAM file through the command line
+    refs = ann.chrom_names + ['chrUn_GL456239']
+    tid, pos, flag, mapq = bam.units_to_records(units, len(refs) - 1, paired=True)
+    path, idx, out = str(tmp_path / 'cfg1.bam'), str(tmp_path / 'mm10.tecidx'), str(tmp_path / 'cfg1.tsv')
+    bam.write_bam_arrays(path, refs, tid, pos, flag, mapq, pair_names=True)
+    ann.flat.save(idx)
+    cli.main(['-i', path, '-o', out, '-g', idx, '-m', 'custom'])
+    result = {n: int(c) for n, c in zip(ann.flat.names, want)}
+    assert open(out).read() == orc.format_bulk_tsv(result, n_units + 1)
+
+
+def test_config4_full_size_single_cell():
+    """BASELINE config 4 at full size: 10 k cells x 5 k reads = 50 M SE records, 737 280-barcode
+    whitelist, 12-mer UMIs, full hg38-like annotation, bundle threshold 1e7 (several spill epochs).
+    Checked through properties: the result does not depend on how the file is cut into batches, every
+    record is accounted for, per-cell totals add up; a 150 k-record run of the same generator on
+    the same annotation is compared bit for bit with the Python oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_sc
+    ann = synth.make_annotation('hg38')
+    eng = Engine(0)
+    eng.upload_index(ann.flat)
+    arrays, wl, tables = synth.make_sc_arrays(ann, 50_000_000, n_cells=10000, seed=2004)
+    n = len(arrays['pos'])
+    assert n > 49_000_000 and wl.shape[0] == 737280
+    outs = []
+    for batch in (1 << 22, 5_000_011):
+        out, st, _, (ids, counts) = bench_sc.run(eng, arrays, wl, tables, 10000, False, 10_000_000, batch=batch)
+        outs.append((out, st, ids, counts))
+    out, st, ids, counts = outs[0]
+    assert st['bundles'] >= 2 and st['records'] == n
+    # conservation: every record is filtered by exactly one rule or survives
+    assert st['qcfail'] + st['lowq'] + st['invalid_barcode'] + st['skipped_chrom'] + st['survivors'] == n
+    assert st['keys'] <= st['survivors'] and st['kept_lines'] <= st['keys'] + st['bundles'] * 10000
+    assert len(ids) == 10000 and int(counts.sum()) >= st['keys']
+    # per-cell totals: the COO triplets of a cell sum to at least its number of assigned UMIs
+    assert len(out['cells']) <= 10000 and int(out['coo_count'].sum()) >= st['assigned'] > 0
+    assert np.all(np.diff(out['coo_cell'].astype(np.int64) * (1 << 32) + out['coo_name']) > 0)  # sorted, unique
+    o2 = outs[1]
+    assert o2[1] == st and np.array_equal(o2[2], ids) and np.array_equal(o2[3], counts)
+    for k in ('cells', 'cell_hits', 'coo_cell', 'coo_name', 'coo_count'):
+        assert np.array_equal(o2[0][k], out[k]), k
+    del arrays, outs, o2
+    # oracle sample: same generator, same (full) annotation, 150 k records, 40 cells, several epochs
+    from oracle import te_oracle as orc
+    arrays, wl, tables = synth.make_sc_arrays(ann, 150_000, n_cells=40, n_whitelist=5000, seed=2014)
+    out, st, _, _ = bench_sc.run(eng, arrays, wl, tables, 25, True, 12_000, batch=40_000)
+    assert st['bundles'] >= 3
+    wl_str = [bytes(r).rstrip(b'\0').decode() for r in wl]
+    recs = synth.sc_arrays_to_records(arrays, tables[0])
+    # the oracle needs feature dicts: only features that overlap a record's window can be hit (5.7 M dicts otherwise)
+    f = ann.flat
+    feats = synth.features_overlapping(f, tables[1][arrays['cls']], arrays['pos'] - 8, arrays['end'] + 8)
+    assert 1000 < len(feats) < 600_000
+    want, wbc, _ = orc.sc_count(feats, recs, wl_str, 25, strand=True, bundle_threshold=12_000)
+    got = {}
+    for c, nm, v in zip(out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()):
+        got.setdefault(f.names[nm], {})[wl_str[c]] = v
+    assert got == {k: v for k, v in want.items() if v}
+    assert [(wl_str[c], h) for c, h in zip(out['cells'].tolist(), out['cell_hits'].tolist())] == list(wbc.items())
+    eng.close()
 
 
 def test_custom_3M_interval_annotation():
