@@ -192,6 +192,10 @@ int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n_whitelist,
 int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const int32_t* pos, const int32_t* end,
                   const uint16_t* flag, const uint8_t* mapq, const uint8_t* cb24, const uint8_t* ub24,
                   const uint8_t* tagflags);
+/* Same, for a batch that is already resident in HBM (device pointers). */
+int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
+                         const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb24, const uint8_t* d_ub24,
+                         const uint8_t* d_tagflags);
 /* Part 1 (te_count.py:371-476).  Returns TEC_ENOCB / TEC_ENOUB where the reference asserts.
  * *n_cells_seen = number of barcodes with a non-zero raw count. */
 int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen);
@@ -226,6 +230,19 @@ int tec_sc_end(tec_ctx* ctx);
  */
 typedef struct tec_bam tec_bam;
 int tec_bam_open(const char* path, int n_threads, tec_bam** out);
+/* Multi-GPU decoding: one reader per rank over a byte range [range_begin, range_end) of the compressed
+ * file.  The reader delivers exactly the records that START inside a BGZF block whose file offset lies
+ * in the range (a record that straddles into the next range is completed from the following blocks).
+ * A range that does not begin at 0 finds its first BGZF block by the block header's fixed bytes and
+ * GUESSES its first record start (field plausibility over three consecutive records); the caller makes
+ * the decomposition exact by comparing tokens: range k's end token -- {file offset of the BGZF block,
+ * offset inside its inflated bytes} of the first record it does NOT own -- must equal range k+1's first
+ * token.  The reference reads the file front to back with one pysam iterator (te_count.py:65,78-79). */
+int tec_bam_open_range(const char* path, int n_threads, uint64_t range_begin, uint64_t range_end, tec_bam** out);
+/* Valid after the reader has returned its last record (*finished != 0).  *has_first == 0: no record
+ * starts in this range. */
+int tec_bam_range_tokens(tec_bam* r, uint64_t first[2], uint64_t end[2], int* has_first, int* finished);
+uint64_t tec_bam_file_size(const tec_bam* r);
 void tec_bam_close(tec_bam* r);
 /* Raw DEFLATE (RFC 1951) of one BGZF block body into exactly out_len bytes: the decoder the BAM
  * reader uses in place of pysam / htslib (te_count.py:65, 190, 351); use_zlib != 0 runs zlib's
@@ -234,9 +251,67 @@ int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t o
 
 const char* tec_bam_last_error(const tec_bam* r);
 int tec_bam_n_refs(const tec_bam* r);
+uint32_t tec_bam_ref_len(const tec_bam* r, int i);
 const char* tec_bam_ref_name(const tec_bam* r, int i);
 int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int32_t* pos, int32_t* end, uint16_t* flag,
                  uint8_t* mapq, uint64_t* qkey, uint8_t* cb24, uint8_t* ub24, uint8_t* tagflags, uint64_t* n_out);
+
+/* ---- Alignment decoding ON THE GPU ----------------------------------------------------------
+ * The same boundary as tec_bam_* (pysam.AlignmentFile + next(sam), te_count.py:65,78-98 / 190,203-214 /
+ * 351,393-438) for BGZF-compressed BAM files, with the decoding moved to the MI355X: the host copies
+ * the COMPRESSED file bytes into pinned memory and on to HBM; a kernel inflates the BGZF blocks (one
+ * lane per block), kernels find the record boundaries, extract the fields the reference reads and --
+ * for PE -- pair consecutive records; the resulting rows feed tec_bulk_submit_device /
+ * tec_sc_submit_device directly.  Results are those of the host decoder bit for bit (a block the
+ * inflate kernel refuses is redone by the host decoder; record boundaries are verified, not guessed).
+ *
+ * range_begin / range_end: byte range of the compressed file owned by this reader (0, UINT64_MAX = the
+ * whole file); ownership and token rules as for tec_bam_open_range. */
+typedef struct tec_gbam tec_gbam;
+typedef struct tec_gbam_rec {  /* the fields of one record that PE pairing needs (te_count.py:81-98) */
+    int32_t chrom;             /* index chromosome id of the record's reference, -1: not in the index */
+    int32_t pos;
+    uint16_t flag;
+    uint8_t mapq;
+    uint64_t qkey;             /* hash of the mate-name key (te_count.py:92) */
+} tec_gbam_rec;
+typedef struct tec_gbam_report {
+    uint64_t n_records;            /* records owned by this reader */
+    int has_records;
+    uint64_t first_token[2], end_token[2];
+    uint64_t first_noend_live;     /* SE: ordinal of the first record that passes every filter but has no CIGAR
+                                      (pysam: reference_end None -> the reference dies, te_count.py:223); ~0: none */
+    uint64_t first_name_mismatch;  /* PE: unit ordinal of the first live pair whose mate names differ
+                                      (the reference dies, te_count.py:92-94); ~0: none */
+    uint64_t units_counted;        /* PE, not deferred: pairs handed to the count kernel */
+    int odd_record_left;           /* PE, not deferred: a last unpaired record was dropped (te_count.py:78-79) */
+    tec_gbam_rec first_rec, last_rec; /* PE, deferred: for the cross-range pairing */
+    uint64_t blocks, blocks_redone_on_host, compressed_bytes, inflated_bytes, segment_repairs;
+} tec_gbam_report;
+int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begin, uint64_t range_end, tec_gbam** out);
+void tec_gbam_close(tec_gbam* g);
+const char* tec_gbam_last_error(const tec_gbam* g);
+int tec_gbam_n_refs(const tec_gbam* g);
+const char* tec_gbam_ref_name(const tec_gbam* g, int i);
+uint64_t tec_gbam_file_size(const tec_gbam* g);
+/* Bulk (after tec_bulk_begin): decodes the reader's records and counts them.  tid_to_chrom[tid]: index
+ * chromosome id or -1 (te_count.py:96-102, 212-218).  paired: units are pairs of consecutive records.
+ * defer_pairing (multi-GPU PE): keep the records resident in HBM instead of pairing them, because
+ * which records are mates depends on the parity of the number of records in the ranges before this one;
+ * finish with tec_gbam_finish_pairs once that is known. */
+int tec_gbam_run_bulk(tec_gbam* g, int paired, int mapq_min, const int32_t* tid_to_chrom, uint32_t n_tid, int defer_pairing,
+                      tec_gbam_report* rep);
+int tec_gbam_finish_pairs(tec_gbam* g, int mapq_min, int skip_first, const tec_gbam_rec* extra_mate, uint64_t unit_ordinal0,
+                          uint64_t* n_units, uint64_t* first_name_mismatch);
+/* Single cell (after tec_sc_begin): tid_to_class[tid] = read-side chromosome class (tec_sc_begin). */
+int tec_gbam_run_sc(tec_gbam* g, int mapq_min, const int32_t* tid_to_class, uint32_t n_tid, tec_gbam_report* rep);
+
+/* Decode only: the reader's records stay resident in HBM (tid = BAM reference id, end = INT32_MIN without a
+ * CIGAR, qkey / cb24 / ub24 / tagflags as for tec_bam_read); tec_gbam_fetch copies rows [first, first + n)
+ * to host arrays (any pointer may be NULL). */
+int tec_gbam_decode(tec_gbam* g, tec_gbam_report* rep);
+int tec_gbam_fetch(tec_gbam* g, uint64_t first, uint64_t n, int32_t* tid, int32_t* pos, int32_t* end, uint16_t* flag,
+                   uint8_t* mapq, uint64_t* qkey, uint8_t* cb24, uint8_t* ub24, uint8_t* tagflags);
 
 /* ---- Dense single-cell TSV (the step after the path) ----------------------------------------
  * Replaces the densifying loops of measureTE.sc_save_result (te_count.py:744-754).  header: the

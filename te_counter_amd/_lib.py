@@ -67,9 +67,25 @@ _SIGNATURES = {
     'tec_write_dense_tsv': (C.c_int, [C.c_char_p, C.c_char_p, _u64, C.c_uint32, C.c_uint32, C.c_char_p, _p, _u64, _p, _p, _p]),
     'tec_inflate_raw': (C.c_int, [_p, _u64, _p, _u64, C.c_int]),
     'tec_bam_open': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_p)]),
+    'tec_bam_open_range': (C.c_int, [C.c_char_p, C.c_int, _u64, _u64, C.POINTER(_p)]),
+    'tec_bam_range_tokens': (C.c_int, [_p, _p, _p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'tec_bam_file_size': (_u64, [_p]),
     'tec_bam_close': (None, [_p]),
     'tec_bam_last_error': (C.c_char_p, [_p]),
     'tec_bam_n_refs': (C.c_int, [_p]),
+    'tec_bam_ref_len': (C.c_uint32, [_p, C.c_int]),
+    'tec_gbam_open': (C.c_int, [_p, C.c_char_p, _u64, _u64, C.POINTER(_p)]),
+    'tec_gbam_close': (None, [_p]),
+    'tec_gbam_last_error': (C.c_char_p, [_p]),
+    'tec_gbam_n_refs': (C.c_int, [_p]),
+    'tec_gbam_ref_name': (C.c_char_p, [_p, C.c_int]),
+    'tec_gbam_file_size': (_u64, [_p]),
+    'tec_gbam_run_bulk': (C.c_int, [_p, C.c_int, C.c_int, _p, C.c_uint32, C.c_int, _p]),
+    'tec_gbam_finish_pairs': (C.c_int, [_p, C.c_int, C.c_int, _p, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
+    'tec_gbam_run_sc': (C.c_int, [_p, C.c_int, _p, C.c_uint32, _p]),
+    'tec_gbam_decode': (C.c_int, [_p, _p]),
+    'tec_gbam_fetch': (C.c_int, [_p, _u64, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'tec_sc_submit_device': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),
     'tec_bam_ref_name': (C.c_char_p, [_p, C.c_int]),
     'tec_bam_read': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_u64)]),
 }

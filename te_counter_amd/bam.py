@@ -16,11 +16,24 @@ from .reads import TAG_BYTES, RecordBatch
 NO_END = -2 ** 31  # reference_end of a record without CIGAR (pysam gives None)
 
 
+def byte_range(file_size, rank, world):
+    """The slice of the compressed file rank `rank` of `world` decodes: equal byte shares; a reader owns
+    the records that start in BGZF blocks starting inside its share (include/tecount.h)."""
+    return (file_size * rank) // world, (file_size * (rank + 1)) // world
+
+
 class BamSource:
-    def __init__(self, path, batch_size=1 << 22, threads=0):
+    """Host-side decoder (csrc/bamio.hip).  byte_range = (begin, end): deliver only the records owned by
+    that slice of the compressed file (multi-GPU sharded decoding); None: the whole file."""
+
+    def __init__(self, path, batch_size=1 << 22, threads=0, byte_range=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        rc = self._lib.tec_bam_open(str(path).encode(), int(threads), C.byref(self._h))
+        if byte_range is None:
+            rc = self._lib.tec_bam_open(str(path).encode(), int(threads), C.byref(self._h))
+        else:
+            rc = self._lib.tec_bam_open_range(str(path).encode(), int(threads), int(byte_range[0]), int(byte_range[1]),
+                                              C.byref(self._h))
         if rc != _lib.TEC_OK:
             msg = self._lib.tec_bam_last_error(None)
             raise IOError('cannot read %s: %s' % (path, msg.decode() if msg else '?'))
@@ -94,6 +107,17 @@ class BamSource:
             if k < n:
                 return
 
+    def range_tokens(self):
+        """(first, end, has_first): where this reader's first record and the first record it does NOT own
+        start, each as (BGZF block file offset, offset inside the inflated block).  Valid once the last
+        record has been delivered; the multi-rank job checks end[k] == first[k+1] (dist.check_ranges)."""
+        first, end = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        hf, fin = C.c_int(), C.c_int()
+        self._lib.tec_bam_range_tokens(self._h, first, end, C.byref(hf), C.byref(fin))
+        if not fin.value:
+            raise RuntimeError('range tokens are only known after the last record has been read')
+        return (first[0], first[1]), (end[0], end[1]), bool(hf.value)
+
     def close(self):
         if self._h:
             self._lib.tec_bam_close(self._h)
@@ -106,8 +130,8 @@ class BamSource:
             pass
 
 
-def open_alignment(path, batch_size=1 << 22, threads=0):
-    return BamSource(path, batch_size=batch_size, threads=threads)
+def open_alignment(path, batch_size=1 << 22, threads=0, byte_range=None):
+    return BamSource(path, batch_size=batch_size, threads=threads, byte_range=byte_range)
 
 
 # --------------------------------------------------------------------------- writer (tests, synthetic data)
@@ -184,7 +208,7 @@ def units_to_records(units, spare_tid, paired):
 def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair_names=False, cb=None, ub=None,
                      payload='random', seed=1, threads=0, level=1, reference_length=300000000):
     """Vectorised BAM writer for large synthetic inputs (numpy + zlib, BGZF blocks of 0xff00 bytes
-    compressed on a thread pool).  One fixed-width record per read: a 27-character Illumina-style
+    compressed on a thread pool).  One fixed-width record per read: a 28-character Illumina-style
     name (mates share it up to '/1' '/2' when pair_names), CIGAR 50M <gap>N 50M (gap = end - pos - 100,
     0 when `end` is None), 100 bases + qualities, NH/HI/AS/nM tags and, if given, CB / UB 'Z' tags
     (uint8[n, 24] zero padded, all of one length).
@@ -194,7 +218,7 @@ def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair
     import os
     n = len(tid)
     rng = np.random.default_rng(seed)
-    name_len = 28
+    name_len = 29  # 28 characters + NUL
     fields = [('bs', '<u4'), ('tid', '<i4'), ('pos', '<i4'), ('l_name', 'u1'), ('mapq', 'u1'), ('bin', '<u2'),
               ('n_cig', '<u2'), ('flag', '<u2'), ('l_seq', '<u4'), ('ntid', '<i4'), ('npos', '<i4'), ('tlen', '<i4'),
               ('name', 'S%d' % name_len), ('cigar', '<u4', 3), ('seq', 'u1', 50), ('qual', 'u1', 100), ('aux', 'S16')]
@@ -212,7 +236,7 @@ def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair
     ordinal = (np.arange(n) // 2) if pair_names else np.arange(n)
     names = np.char.add(np.char.add('A00123:45:HXX:1:', np.char.zfill(ordinal.astype(str), 10)), '/')
     names = np.char.add(names, np.where(np.arange(n) % 2 == 0, '1', '2')) if pair_names else np.char.add(names, '1')
-    rec['name'] = names.astype('S%d' % name_len)  # NUL padded: 27 chars + NUL
+    rec['name'] = names.astype('S%d' % name_len)  # NUL padded: 28 characters + NUL
     gap = np.zeros(n, np.int64) if end is None else np.asarray(end, np.int64) - np.asarray(pos, np.int64) - 100
     if (gap < 0).any():
         raise ValueError('end must be >= pos + 100')

@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 #include <vector>
 
+#include "bamscan.h"
 #include "inflate_fast.h"
 #include "tecount_internal.h"
 
@@ -72,6 +73,21 @@ struct tec_bam {
     bool file_eof = false;
     int n_threads = 4;
     uint64_t n_records = 0;
+    // byte-range ownership (tec_bam_open_range): this reader delivers the records that START inside a
+    // BGZF block whose file offset lies in [range_begin, range_end)
+    bool ranged = false;
+    uint64_t range_begin = 0, range_end = ~0ull;
+    bool owned_done = false;     // every owned block has been inflated into the window
+    bool in_epilogue = false;    // completing the last owned record from blocks beyond range_end
+    bool finished = false;       // the end token has been computed
+    struct WinBlock {
+        int64_t win_off;    // of the block's first inflated byte relative to buf (negative: the block straddles the front)
+        uint64_t file_off;  // of the BGZF block in the file
+        uint32_t isize;
+    };
+    std::vector<WinBlock> wblocks;  // the blocks whose inflated bytes are (still) in the window
+    uint64_t tok_first[2] = {0, 0}, tok_end[2] = {0, 0};  // {BGZF block file offset, offset inside its inflated bytes}
+    bool have_first = false;
     // SAM text state
     std::string line;
 };
@@ -87,6 +103,7 @@ int bam_fail(tec_bam* r, int code, const std::string& msg) {
 }
 
 struct RawBlock {
+    uint64_t file_off = 0;  // of the BGZF block (mapped files)
     size_t off = 0;  // of the DEFLATE body inside r->raw
     size_t clen = 0;
     uint32_t isize = 0;
@@ -132,6 +149,22 @@ bool raw_ensure(tec_bam* r, size_t need) {
 }
 size_t raw_left(const tec_bam* r) { return (r->map ? r->map_len : r->raw.size()) - r->raw_pos; }
 
+// Drops the consumed front of the inflate window.  Block positions are signed: a block that
+// straddles the new front keeps a negative offset, so window byte p is byte p - win_off of its block.
+void compact_window(tec_bam* r) {
+    const size_t k = r->buf_pos;
+    if (!k) return;
+    r->buf.drop_front(k);
+    r->buf_pos = 0;
+    size_t keep = 0;
+    for (const auto& w : r->wblocks) {
+        if (w.win_off + (int64_t)w.isize <= (int64_t)k) continue;  // wholly consumed
+        r->wblocks[keep] = w;
+        r->wblocks[keep++].win_off -= (int64_t)k;
+    }
+    r->wblocks.resize(keep);
+}
+
 // Finds up to max_blocks BGZF blocks at the read position; *total = their inflated size.
 int discover_blocks(tec_bam* r, size_t max_blocks, std::vector<RawBlock>* blocks, size_t* total) {
     blocks->clear();
@@ -142,9 +175,14 @@ int discover_blocks(tec_bam* r, size_t max_blocks, std::vector<RawBlock>* blocks
         r->raw_pos = 0;
     }
     while (blocks->size() < max_blocks) {
+        if (r->ranged && !r->in_epilogue && r->raw_pos >= r->range_end) {  // the next block belongs to the next range
+            r->owned_done = true;
+            break;
+        }
         if (!raw_ensure(r, 18)) {
             if (raw_left(r) == 0) {
                 r->eof = true;
+                r->owned_done = true;
                 break;
             }
             return bam_fail(r, TEC_EINVAL, "not a BGZF block (truncated or not a BAM file)");
@@ -169,6 +207,7 @@ int discover_blocks(tec_bam* r, size_t max_blocks, std::vector<RawBlock>* blocks
         if (!raw_ensure(r, (size_t)bsize + 1)) return bam_fail(r, TEC_EINVAL, "truncated BGZF block");
         const uint8_t* tail = raw_base(r) + r->raw_pos + 12 + xlen + (size_t)clen;
         RawBlock b;
+        b.file_off = r->raw_pos;
         b.off = r->raw_pos + 12 + xlen;
         b.clen = (size_t)clen;
         b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
@@ -184,23 +223,39 @@ int discover_blocks(tec_bam* r, size_t max_blocks, std::vector<RawBlock>* blocks
 // Reads up to max_blocks BGZF blocks and appends their inflated bytes to r->buf (header parsing;
 // the record path inflates inside read_chunk below).
 int refill(tec_bam* r, size_t max_blocks) {
-    if (r->buf_pos) {
-        r->buf.drop_front(r->buf_pos);
-        r->buf_pos = 0;
-    }
+    compact_window(r);
     std::vector<RawBlock> blocks;
     size_t total = 0;
     const int k = discover_blocks(r, max_blocks, &blocks, &total);
     if (k <= 0) return k;
     const size_t base = r->buf.size();
+    for (const RawBlock& b : blocks) r->wblocks.push_back({(int64_t)(base + b.out_off), b.file_off, b.isize});
     if (!r->buf.grow(total)) return bam_fail(r, TEC_EINVAL, "out of memory for the inflate window");
     std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
     for (const RawBlock& b : blocks)
         if (b.isize && !inflate_one(raw_base(r) + b.off, b.clen, r->buf.data() + base + b.out_off, b.isize, tabs.get())) {
             r->buf.n = base;  // the window holds nothing of this refill
+            while (!r->wblocks.empty() && r->wblocks.back().win_off >= (int64_t)base) r->wblocks.pop_back();
             return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
         }
     return 1;
+}
+
+// Window offset where inflated bytes of blocks beyond the owned range begin (SIZE_MAX: none in the window).
+size_t own_limit(const tec_bam* r) {
+    if (!r->ranged) return SIZE_MAX;
+    for (const auto& w : r->wblocks)
+        if (w.file_off >= r->range_end) return w.win_off > 0 ? (size_t)w.win_off : 0;
+    return SIZE_MAX;
+}
+
+// refill() that keeps the window's front where it is (buf_pos is 0 while the first record of a range is searched)
+int refill_keep(tec_bam* r, size_t max_blocks) {
+    const size_t save = r->buf_pos;
+    r->buf_pos = 0;
+    const int k = refill(r, max_blocks);
+    r->buf_pos = save;
+    return k;
 }
 
 // Makes at least `need` unread bytes available; returns false at a clean end of stream.
@@ -218,25 +273,8 @@ bool ensure(tec_bam* r, size_t need, int* rc) {
 }
 
 inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
-inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-// '_'.join(qname.split('/')[0:-1]) (te_count.py:92) hashed: names are only compared for equality
-uint64_t mate_key_hash(const char* q, size_t n) {
-    size_t last = n;  // position of the last '/'
-    bool any = false;
-    for (size_t i = 0; i < n; ++i)
-        if (q[i] == '/') {
-            last = i;
-            any = true;
-        }
-    uint64_t h = 1469598103934665603ull;
-    if (!any) return h;  // no '/': the key is the empty string
-    for (size_t i = 0; i < last; ++i) {
-        const char c = q[i] == '/' ? '_' : q[i];
-        h = (h ^ (uint8_t)c) * 1099511628211ull;
-    }
-    return h;
-}
+uint64_t mate_key_hash(const char* q, size_t n) { return tec_bamscan::mate_key_hash((const uint8_t*)q, n); }
 
 struct OutArrays {
     int32_t *tid, *pos, *end;
@@ -254,50 +292,6 @@ void put_tag(uint8_t* dst24, const char* v, size_t n, uint8_t* tf, uint8_t prese
     }
     memset(dst24, 0, 24);
     memcpy(dst24, v, n);
-}
-
-// Aux walk of one BAM record: picks CB (else CR) and UB (else UR) 'Z' values.
-void scan_aux(const uint8_t* p, const uint8_t* e, uint8_t* cb24, uint8_t* ub24, uint8_t* tf) {
-    const char *cb = nullptr, *cr = nullptr, *ub = nullptr, *ur = nullptr;
-    size_t ncb = 0, ncr = 0, nub = 0, nur = 0;
-    while (p + 3 <= e) {
-        const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
-        p += 3;
-        size_t sz = 0;
-        switch (ty) {
-            case 'A': case 'c': case 'C': sz = 1; break;
-            case 's': case 'S': sz = 2; break;
-            case 'i': case 'I': case 'f': sz = 4; break;
-            case 'Z': case 'H': {
-                const uint8_t* z = (const uint8_t*)memchr(p, 0, (size_t)(e - p));
-                if (!z) return;
-                if (ty == 'Z') {
-                    const size_t n = (size_t)(z - p);
-                    if (t0 == 'C' && t1 == 'B') { cb = (const char*)p; ncb = n; }
-                    else if (t0 == 'C' && t1 == 'R') { cr = (const char*)p; ncr = n; }
-                    else if (t0 == 'U' && t1 == 'B') { ub = (const char*)p; nub = n; }
-                    else if (t0 == 'U' && t1 == 'R') { ur = (const char*)p; nur = n; }
-                }
-                p = z + 1;
-                continue;
-            }
-            case 'B': {
-                if (p + 5 > e) return;
-                const char st = (char)p[0];
-                const uint32_t cnt = le32(p + 1);
-                const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
-                sz = 5 + (size_t)cnt * es;
-                break;
-            }
-            default: return;  // unknown type: stop (cannot know its size)
-        }
-        if ((size_t)(e - p) < sz) return;
-        p += sz;
-    }
-    if (cb) put_tag(cb24, cb, ncb, tf, 1, 4);
-    else if (cr) put_tag(cb24, cr, ncr, tf, 1, 4);
-    if (ub) put_tag(ub24, ub, nub, tf, 2, 8);
-    else if (ur) put_tag(ub24, ur, nur, tf, 2, 8);
 }
 
 int read_bam_header(tec_bam* r) {
@@ -454,7 +448,89 @@ extern "C" int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out,
 
 extern "C" const char* tec_bam_last_error(const tec_bam* r) { return r ? r->err.c_str() : g_bam_err.c_str(); }
 
+namespace {
+// First BGZF block at or after file offset `from`: the 16 fixed header bytes (magic, FEXTRA, XLEN = 6, 'BC', SLEN = 2) and
+// a chain of three consecutive blocks that look the same (or the end of the file).
+bool bgzf_header_at(const uint8_t* m, size_t len, size_t o, size_t* bsize) {
+    if (len - o < 18) return false;
+    const uint8_t* h = m + o;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || h[3] != 4 || h[10] != 6 || h[11] != 0 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 ||
+        h[15] != 0)
+        return false;
+    *bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
+    return *bsize >= 26 && o + *bsize <= len;
+}
+size_t find_bgzf_block(const uint8_t* m, size_t len, size_t from) {
+    for (size_t o = from; o + 18 <= len; ++o) {
+        if (m[o] != 31 || m[o + 1] != 139) continue;
+        size_t p = o, bs = 0;
+        int good = 0;
+        while (good < 3 && p < len && bgzf_header_at(m, len, p, &bs)) {
+            p += bs;
+            ++good;
+        }
+        if (good == 3 || (good > 0 && p == len)) return o;
+    }
+    return len;
+}
+}  // namespace
+
+// ---- BGZF helpers shared with the on-GPU decoder (gbam.hip)
+size_t tec_bgzf_find_block(const uint8_t* m, size_t len, size_t from) { return find_bgzf_block(m, len, from); }
+
+// Header of the BGZF block at m + o (general form: any extra subfields).  false: not a complete block.
+bool tec_bgzf_parse(const uint8_t* m, size_t len, size_t o, size_t* bsize, size_t* body_off, size_t* body_len, uint32_t* isize) {
+    if (len - o < 18) return false;
+    const uint8_t* h = m + o;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+    const size_t xlen = h[10] | (h[11] << 8);
+    if (len - o < 12 + xlen) return false;
+    long bs = -1;
+    for (size_t x = 0; x + 4 <= xlen;) {
+        const size_t slen = h[12 + x + 2] | (h[12 + x + 3] << 8);
+        if (h[12 + x] == 'B' && h[12 + x + 1] == 'C' && slen == 2 && x + 6 <= xlen) bs = h[12 + x + 4] | (h[12 + x + 5] << 8);
+        x += 4 + slen;
+    }
+    if (bs < 0) return false;
+    const long clen = bs + 1 - 12 - (long)xlen - 8;
+    if (clen < 0 || len - o < (size_t)bs + 1) return false;
+    *bsize = (size_t)bs + 1;
+    *body_off = o + 12 + xlen;
+    *body_len = (size_t)clen;
+    const uint8_t* t = m + o + *bsize - 4;
+    *isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+    return *isize <= 65536u;
+}
+
+// The referee: inflates one block body on the host (fast decoder, then zlib).
+bool tec_bgzf_inflate_host(const uint8_t* body, size_t body_len, uint8_t* out, uint32_t isize) {
+    if (!isize) return true;
+    std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
+    return inflate_one(body, body_len, out, isize, tabs.get());
+}
+
+static int bam_open_impl(const char* path, int n_threads, uint64_t range_begin, uint64_t range_end, bool ranged, tec_bam** out);
+
 extern "C" int tec_bam_open(const char* path, int n_threads, tec_bam** out) {
+    return bam_open_impl(path, n_threads, 0, ~0ull, false, out);
+}
+
+extern "C" int tec_bam_open_range(const char* path, int n_threads, uint64_t range_begin, uint64_t range_end, tec_bam** out) {
+    return bam_open_impl(path, n_threads, range_begin, range_end, true, out);
+}
+
+extern "C" int tec_bam_range_tokens(tec_bam* r, uint64_t first[2], uint64_t end[2], int* has_first, int* finished) {
+    if (!r) return TEC_EINVAL;
+    if (first) { first[0] = r->tok_first[0]; first[1] = r->tok_first[1]; }
+    if (end) { end[0] = r->tok_end[0]; end[1] = r->tok_end[1]; }
+    if (has_first) *has_first = r->have_first ? 1 : 0;
+    if (finished) *finished = r->finished ? 1 : 0;
+    return TEC_OK;
+}
+
+extern "C" uint64_t tec_bam_file_size(const tec_bam* r) { return r && r->map ? (uint64_t)r->map_len : 0; }
+
+static int bam_open_impl(const char* path, int n_threads, uint64_t range_begin, uint64_t range_end, bool ranged, tec_bam** out) {
     if (!path || !out) return bam_fail(nullptr, TEC_EINVAL, "tec_bam_open: NULL argument");
     *out = nullptr;
     FILE* fh = fopen(path, "rb");
@@ -484,13 +560,75 @@ extern "C" int tec_bam_open(const char* path, int n_threads, tec_bam** out) {
             }
         }
     }
-    const int rc = r->is_bam ? read_bam_header(r) : read_sam_header(r);
-    if (rc != TEC_OK) {
+    int rc = r->is_bam ? read_bam_header(r) : read_sam_header(r);
+    auto bail = [&](int code) {
         g_bam_err = r->err;
         if (r->map) munmap(const_cast<uint8_t*>(r->map), r->map_len);
         fclose(fh);
         delete r;
-        return rc;
+        return code;
+    };
+    if (rc != TEC_OK) return bail(rc);
+    if (ranged) {
+        if (!r->is_bam || !r->map) return bail(bam_fail(r, TEC_EINVAL, "byte ranges need a BAM file that can be mapped"));
+        r->ranged = true;
+        r->range_begin = range_begin;
+        r->range_end = range_end;
+    }
+    if (r->is_bam && r->map) {
+        if (ranged && range_begin > 0) {
+            // not the first range: start at the first BGZF block inside it and GUESS the first record
+            // start there (bamscan.h plausible_record); the guess is verified against the previous
+            // range's end token by the caller
+            r->buf.n = 0;
+            r->buf_pos = 0;
+            r->wblocks.clear();
+            r->eof = false;
+            r->raw_pos = find_bgzf_block(r->map, r->map_len, (size_t)std::min<uint64_t>(range_begin, r->map_len));
+            std::vector<uint32_t> lens(r->ref_lens);
+            size_t x = 0;
+            bool found = false;
+            for (;;) {
+                const size_t n = r->buf.size();
+                for (; x + 36 <= n && !found; ++x)
+                    if (tec_bamscan::plausible_record(r->buf.data(), n, x, (int32_t)r->ref_names.size(), lens.data(), 3)) {
+                        // the record must start in an owned block
+                        found = true;
+                        break;
+                    }
+                if (found || r->owned_done || r->eof) break;
+                rc = refill_keep(r, 4);
+                if (rc < 0) return bail(rc);
+            }
+            if (found) {
+                r->buf_pos = x;
+                bool in_owned = false;
+                for (const auto& w : r->wblocks)
+                    if ((int64_t)x >= w.win_off && (int64_t)x < w.win_off + (int64_t)w.isize) {
+                        r->tok_first[0] = w.file_off;
+                        r->tok_first[1] = (uint64_t)((int64_t)x - w.win_off);
+                        in_owned = w.file_off < r->range_end;
+                    }
+                r->have_first = in_owned;
+                if (!in_owned) found = false;
+            }
+            if (!found) {  // no record starts in this range
+                r->buf.n = 0;
+                r->buf_pos = 0;
+                r->owned_done = true;
+                r->finished = true;
+                r->have_first = false;
+            }
+        } else {
+            // the first range (or the whole file): records start right after the header
+            for (const auto& w : r->wblocks)
+                if ((int64_t)r->buf_pos >= w.win_off && (int64_t)r->buf_pos < w.win_off + (int64_t)w.isize) {
+                    r->tok_first[0] = w.file_off;
+                    r->tok_first[1] = (uint64_t)((int64_t)r->buf_pos - w.win_off);
+                    r->have_first = true;
+                }
+            if (ranged && r->raw_pos >= r->range_end) r->owned_done = true;
+        }
     }
     *out = r;
     return TEC_OK;
@@ -504,45 +642,25 @@ extern "C" void tec_bam_close(tec_bam* r) {
 }
 
 extern "C" int tec_bam_n_refs(const tec_bam* r) { return r ? (int)r->ref_names.size() : -1; }
+extern "C" uint32_t tec_bam_ref_len(const tec_bam* r, int i) {
+    return (r && i >= 0 && (size_t)i < r->ref_lens.size()) ? r->ref_lens[i] : 0;
+}
 extern "C" const char* tec_bam_ref_name(const tec_bam* r, int i) {
     return (r && i >= 0 && (size_t)i < r->ref_names.size()) ? r->ref_names[i].c_str() : nullptr;
 }
 
-// One record (p points at its block_size field, the whole record is in memory) -> row w of the SoA.
+// One record (rec points at its block_size field, the whole record is in memory) -> row w of the SoA.
+// The field rules live in bamscan.h, shared with the on-GPU decoder.
 bool extract_record(const uint8_t* rec, uint64_t w, const OutArrays& a) {
-    const uint8_t* p = rec + 4;
-    const uint32_t bs = le32(rec);
-    const uint8_t* e = p + bs;
-    const int32_t refid = (int32_t)le32(p);
-    const int32_t p0 = (int32_t)le32(p + 4);
-    const unsigned l_name = p[8];
-    const unsigned n_cig = le16(p + 12);
-    const uint32_t l_seq = le32(p + 16);
-    const uint8_t* name = p + 32;
-    const uint8_t* cig = name + l_name;
-    const uint8_t* aux = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + l_seq;
-    if (aux > e) return false;
-    int64_t reflen = 0;
-    for (unsigned c = 0; c < n_cig; ++c) {
-        const uint32_t v = le32(cig + 4 * c);
-        const unsigned op = v & 15u;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;  // M D N = X
-    }
-    a.tid[w] = refid;
-    a.pos[w] = p0;
-    // pysam: reference_end is None without a CIGAR; htslib's bam_endpos counts a CIGAR that consumes
-    // no reference base (only S/I/H/P) as one base
-    a.end[w] = n_cig ? (int32_t)(p0 + (reflen ? reflen : 1)) : INT32_MIN;
-    a.flag[w] = le16(p + 14);
-    a.mapq[w] = p[9];
-    if (a.qkey) a.qkey[w] = mate_key_hash((const char*)name, l_name ? l_name - 1 : 0);
-    if (a.tagflags) {
-        uint8_t tf = 0;
-        memset(a.cb24 + 24 * w, 0, 24);
-        memset(a.ub24 + 24 * w, 0, 24);
-        scan_aux(aux, e, a.cb24 + 24 * w, a.ub24 + 24 * w, &tf);
-        a.tagflags[w] = tf;
-    }
+    tec_bamscan::Core c;
+    if (!tec_bamscan::parse_core(rec, true, &c)) return false;
+    a.tid[w] = c.tid;
+    a.pos[w] = c.pos;
+    a.end[w] = c.end;
+    a.flag[w] = (uint16_t)c.flag;
+    a.mapq[w] = (uint8_t)c.mapq;
+    if (a.qkey) a.qkey[w] = tec_bamscan::mate_key_hash(c.name, c.l_name ? c.l_name - 1 : 0);
+    if (a.tagflags) a.tagflags[w] = (uint8_t)tec_bamscan::scan_tags(c.aux, c.rec_end, a.cb24 + 24 * w, a.ub24 + 24 * w);
     return true;
 }
 
@@ -554,10 +672,7 @@ bool extract_record(const uint8_t* rec, uint64_t w, const OutArrays& a) {
 // and capped the decoder at ~5 M records/s however many threads inflated).
 int read_chunk(tec_bam* r, uint64_t max_left, uint64_t first_row, const OutArrays& a, uint64_t* got) {
     *got = 0;
-    if (r->buf_pos) {
-        r->buf.drop_front(r->buf_pos);
-        r->buf_pos = 0;
-    }
+    compact_window(r);
     std::vector<RawBlock> blocks;
     size_t total = 0;
     // chunk size grows with the thread count: the per-chunk costs (thread start, the baton chain,
@@ -567,6 +682,7 @@ int read_chunk(tec_bam* r, uint64_t max_left, uint64_t first_row, const OutArray
     if (k == 0) return TEC_OK;
     const size_t base = r->buf.size();
     if (!r->buf.grow(total)) return bam_fail(r, TEC_EINVAL, "out of memory for the inflate window");
+    for (const RawBlock& b : blocks) r->wblocks.push_back({(int64_t)(base + b.out_off), b.file_off, b.isize});
     const int nt = std::max(1, std::min<int>(r->n_threads, (int)blocks.size()));
     const size_t per = (blocks.size() + nt - 1) / nt;
     struct Baton {
@@ -640,7 +756,10 @@ int read_chunk(tec_bam* r, uint64_t max_left, uint64_t first_row, const OutArray
         for (auto& x : th) x.join();
     }
     for (int t = 0; t < nt; ++t)
-        if (status[t]) r->buf.n = base;  // a failed chunk leaves nothing in the window
+        if (status[t]) {  // a failed chunk leaves nothing in the window
+            r->buf.n = base;
+            while (!r->wblocks.empty() && r->wblocks.back().win_off >= (int64_t)base) r->wblocks.pop_back();
+        }
     for (int t = 0; t < nt; ++t) {
         if (status[t] == 1) return bam_fail(r, TEC_EINVAL, "BGZF inflate failed (corrupt block)");
         if (status[t] == 2) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
@@ -674,7 +793,7 @@ extern "C" int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int3
     // in the middle of a chunk): sequential, at most one chunk's worth
     {
         size_t pos_b = r->buf_pos;
-        const size_t have = r->buf.size();
+        const size_t have = std::min(r->buf.size(), own_limit(r));
         while (o < max_records && pos_b + 4 <= have) {
             const uint32_t bs = le32(r->buf.data() + pos_b);
             if (bs < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
@@ -686,13 +805,56 @@ extern "C" int tec_bam_read(tec_bam* r, uint64_t max_records, int32_t* tid, int3
         r->buf_pos = pos_b;
     }
     // (B) chunks of up to 512 BGZF blocks: inflate, boundary scan and field extraction fused per thread
-    while (o < max_records && !r->eof) {
+    while (o < max_records && !r->eof && !r->owned_done) {
         uint64_t got = 0;
         const int rc = read_chunk(r, max_records - o, o, a, &got);
         if (rc != TEC_OK) return rc;
         o += got;
     }
-    if (r->eof && o < max_records && r->buf.size() - r->buf_pos != 0) return bam_fail(r, TEC_EINVAL, "truncated BAM record");
+    // (C) the owned blocks are exhausted: a record that STARTS in them but ends in a later range's
+    // blocks is still ours -- complete it from the following blocks; then note where the next
+    // range's first record starts (the end token, compared with that range's own guess)
+    if ((r->eof || r->owned_done) && !r->finished && o < max_records) {
+        r->in_epilogue = true;
+        while (r->buf_pos < std::min(r->buf.size(), own_limit(r))) {  // else: the next record starts in a block that is not ours
+            const size_t have = r->buf.size() - r->buf_pos;
+            bool complete = false;
+            if (have >= 4) {
+                const uint32_t bs = le32(r->buf.data() + r->buf_pos);
+                if (bs < 32) return bam_fail(r, TEC_EINVAL, "corrupt BAM record size");
+                complete = have >= 4 + (size_t)bs;
+            }
+            if (complete) {
+                if (!extract_record(r->buf.data() + r->buf_pos, o, a)) return bam_fail(r, TEC_EINVAL, "corrupt BAM record layout");
+                r->buf_pos += 4 + (size_t)le32(r->buf.data() + r->buf_pos);
+                ++o;
+                break;
+            }
+            const int k = refill(r, 1);
+            if (k < 0) return k;
+            if (k == 0) return bam_fail(r, TEC_EINVAL, "truncated BAM record");
+        }
+        // end token: the block that holds window byte buf_pos (skipping empty blocks; end of file = {file size, 0})
+        for (;;) {
+            bool found = false;
+            for (const auto& w : r->wblocks)
+                if ((int64_t)r->buf_pos >= w.win_off && (int64_t)r->buf_pos < w.win_off + (int64_t)w.isize) {
+                    r->tok_end[0] = w.file_off;
+                    r->tok_end[1] = (uint64_t)((int64_t)r->buf_pos - w.win_off);
+                    found = true;
+                    break;
+                }
+            if (found) break;
+            const int k = refill(r, 1);
+            if (k < 0) return k;
+            if (k == 0) {
+                r->tok_end[0] = r->map ? (uint64_t)r->map_len : ~0ull;
+                r->tok_end[1] = 0;
+                break;
+            }
+        }
+        r->finished = true;
+    }
     *n_out = o;
     r->n_records += o;
     return TEC_OK;

@@ -644,6 +644,48 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
     return TEC_OK;
 }
 
+namespace {
+// Filters + order-preserving compaction of one batch that is resident in HBM (te_count.py:394-433).
+// Returns after the batch has been consumed: the input buffers are free again.
+int sc_ingest(tec_ctx* ctx, tec_sc_state* s, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
+              const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb, const uint8_t* d_ub, const uint8_t* d_tf) {
+    hipStream_t st = ctx->s_compute;
+    SC_HIP(s->b_live.reserve(n));
+    SC_HIP(s->b_scan.reserve(n));
+    SC_HIP(s->b_bcid.reserve(n));
+    hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, d_cls, d_flag, d_mapq, d_cb, d_tf,
+                       s->mapq_min, s->wl.p, s->wl_table.p, s->wl_mask, s->cls_skip.p, s->n_class, s->b_live.p, s->b_bcid.p,
+                       s->stat.p);
+    int rc = scan_u32(ctx, s, s->b_live.p, s->b_scan.p, n, false, rocprim::plus<uint32_t>());
+    if (rc) return rc;
+    uint32_t last_scan = 0, last_live = 0;
+    SC_HIP(hipMemcpyAsync(&last_scan, s->b_scan.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(&last_live, s->b_live.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    const uint64_t add = (uint64_t)last_scan + last_live;
+    const uint64_t need = s->n_live + add;
+    if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
+    // survivor arrays: room for sixteen batches like this one (<= 128 M records) at the first allocation, doubling after that
+    const size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);  // at most 6 GB up front
+    SC_HIP(s->bcid.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->u0.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->u1.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->u2.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->rec.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->klass.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->left.reserve(need, true, s->n_live, floor));
+    SC_HIP(s->rite.reserve(need, true, s->n_live, floor));
+    hipLaunchKernelGGL(sc_scatter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, s->n_live, s->b_live.p,
+                       s->b_scan.p, s->b_bcid.p, d_cls, d_pos, d_end, d_flag, d_ub, s->stranded, s->bcid.p, s->u0.p, s->u1.p,
+                       s->u2.p, s->rec.p, s->klass.p, s->left.p, s->rite.p, s->stat.p);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(st));  // the batch buffers are free again
+    s->n_live = need;
+    s->n_seen += n;
+    return TEC_OK;
+}
+}  // namespace
+
 extern "C" int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const int32_t* pos, const int32_t* end,
                              const uint16_t* flag, const uint8_t* mapq, const uint8_t* cb24, const uint8_t* ub24,
                              const uint8_t* tagflags) {
@@ -671,41 +713,23 @@ extern "C" int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const
     SC_HIP(hipMemcpyAsync(b + o_tf, tagflags, n, hipMemcpyHostToDevice, st));
     SC_HIP(hipMemcpyAsync(b + o_cb, cb24, n * 24, hipMemcpyHostToDevice, st));
     SC_HIP(hipMemcpyAsync(b + o_ub, ub24, n * 24, hipMemcpyHostToDevice, st));
-    SC_HIP(s->b_live.reserve(n));
-    SC_HIP(s->b_scan.reserve(n));
-    SC_HIP(s->b_bcid.reserve(n));
-    hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, (const int32_t*)(b + o_cls),
-                       (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_mq), (const uint8_t*)(b + o_cb),
-                       (const uint8_t*)(b + o_tf), s->mapq_min, s->wl.p, s->wl_table.p, s->wl_mask, s->cls_skip.p, s->n_class, s->b_live.p,
-                       s->b_bcid.p, s->stat.p);
-    int rc = scan_u32(ctx, s, s->b_live.p, s->b_scan.p, n, false, rocprim::plus<uint32_t>());
-    if (rc) return rc;
-    uint32_t last_scan = 0, last_live = 0;
-    SC_HIP(hipMemcpyAsync(&last_scan, s->b_scan.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_HIP(hipMemcpyAsync(&last_live, s->b_live.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_HIP(hipStreamSynchronize(st));
-    const uint64_t add = (uint64_t)last_scan + last_live;
-    const uint64_t need = s->n_live + add;
-    if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
-    // survivor arrays: room for sixteen batches like this one (<= 128 M records) at the first allocation, doubling after that
-    const size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);  // at most 6 GB up front
-    SC_HIP(s->bcid.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->u0.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->u1.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->u2.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->rec.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->klass.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->left.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->rite.reserve(need, true, s->n_live, floor));
-    hipLaunchKernelGGL(sc_scatter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, s->n_live, s->b_live.p,
-                       s->b_scan.p, s->b_bcid.p, (const int32_t*)(b + o_cls), (const int32_t*)(b + o_pos),
-                       (const int32_t*)(b + o_end), (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_ub), s->stranded,
-                       s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p, s->klass.p, s->left.p, s->rite.p, s->stat.p);
-    SC_HIP(hipGetLastError());
-    SC_HIP(hipStreamSynchronize(st));  // host buffers are free again, staging can be reused
-    s->n_live = need;
-    s->n_seen += n;
-    return TEC_OK;
+    return sc_ingest(ctx, s, n, (const int32_t*)(b + o_cls), (const int32_t*)(b + o_pos), (const int32_t*)(b + o_end),
+                     (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_mq), (const uint8_t*)(b + o_cb),
+                     (const uint8_t*)(b + o_ub), (const uint8_t*)(b + o_tf));
+}
+
+extern "C" int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
+                                    const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb24, const uint8_t* d_ub24,
+                                    const uint8_t* d_tagflags) {
+    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "tec_sc_submit_device: call tec_sc_begin first");
+    tec_sc_state* s = ctx->sc;
+    if (s->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_submit_device: after tec_sc_part1");
+    if (n == 0) return TEC_OK;
+    if (!d_cls || !d_pos || !d_end || !d_flag || !d_mapq || !d_cb24 || !d_ub24 || !d_tagflags)
+        return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit_device: NULL array");
+    if (n >= 0x7FFFFFFFull) return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit_device: batch too large");
+    SC_HIP(hipSetDevice(ctx->device));
+    return sc_ingest(ctx, s, n, d_cls, d_pos, d_end, d_flag, d_mapq, d_cb24, d_ub24, d_tagflags);
 }
 
 extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {

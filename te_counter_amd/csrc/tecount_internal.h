@@ -119,3 +119,7 @@ int tec_bulk_init(tec_ctx* ctx);
 int tec_bulk_release(tec_ctx* ctx);
 // sc.hip
 void tec_sc_release(tec_ctx* ctx);
+// bamio.hip: BGZF helpers shared with gbam.hip
+size_t tec_bgzf_find_block(const uint8_t* m, size_t len, size_t from);
+bool tec_bgzf_parse(const uint8_t* m, size_t len, size_t o, size_t* bsize, size_t* body_off, size_t* body_len, uint32_t* isize);
+bool tec_bgzf_inflate_host(const uint8_t* body, size_t body_len, uint8_t* out, uint32_t isize);

@@ -1,10 +1,14 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed, backend nccl == RCCL on ROCm).
 
 The bulk path shards naturally: units are independent and counts are commutative integer sums.
-Every rank decodes the same alignment file and keeps the batches whose ordinal is congruent to
-its rank (batches hold whole PE pairs, so a pair never straddles two ranks); each GPU holds a
-full index replica; the only collective is one sum all-reduce of the u64 count vector (plus the
-five log counters) at the end -- ~330 KB for genes_tes, latency-bound on xGMI.
+Rank r decodes and counts its own byte range of the alignment file (te_counter_amd/bam.py
+byte_range; ownership rules in include/tecount.h) against a full index replica on its GPU; the
+collectives are small:
+  * one all-gather of every range's (record count, first / last record, range tokens) -- the tokens
+    prove that the ranges tile the file exactly, the counts give the parity that decides which
+    records are PE mates (the reference pairs records 2k, 2k+1 of the FILE, te_count.py:78-79);
+  * one sum all-reduce of the u64 count vector and the log counters (~330 KB for genes_tes,
+    latency-bound on xGMI).
 The reference has no distributed path at all.
 """
 
@@ -42,8 +46,13 @@ class World:
         return w
 
     def mine(self, batch_ordinal):
-        """Does this rank count batch number `batch_ordinal` (round-robin sharding)?"""
+        """Does this rank count batch number `batch_ordinal` (round-robin sharding of a source that
+        cannot be cut into byte ranges, e.g. SAM text)?"""
         return batch_ordinal % self.size == self.rank
+
+    def _device(self):
+        import torch
+        return torch.device('cuda', self.local_rank) if self.backend == 'nccl' else torch.device('cpu')
 
     def sum_counts(self, counts, stats_vec):
         """All-reduce (sum) of the per-rank count vector and stats; returns numpy arrays."""
@@ -51,14 +60,88 @@ class World:
             return counts, stats_vec
         import torch
         import torch.distributed as dist
-        dev = torch.device('cuda', self.local_rank) if self.backend == 'nccl' else torch.device('cpu')
-        t = torch.from_numpy(np.concatenate([counts.astype(np.int64), np.asarray(stats_vec, np.int64)])).to(dev)
+        t = torch.from_numpy(np.concatenate([counts.astype(np.int64), np.asarray(stats_vec, np.int64)])).to(self._device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         out = t.cpu().numpy()
         return out[:len(counts)].astype(np.uint64), out[len(counts):]
+
+    def sum_device_counts(self, d_counts_ptr, n_names, stats_vec):
+        """In-place RCCL sum all-reduce of a count vector that lives in HBM (libtecount's own buffer,
+        wrapped without a copy), plus the stats; returns (None, stats) -- the caller reads the reduced
+        vector through the engine."""
+        import torch
+        import torch.distributed as dist
+
+        class _Wrap:
+            __cuda_array_interface__ = {'shape': (n_names,), 'typestr': '<i8', 'data': (d_counts_ptr, False), 'version': 2}
+        t = torch.as_tensor(_Wrap(), device=self._device())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        s = torch.tensor(np.asarray(stats_vec, np.int64), device=self._device())
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        return None, s.cpu().numpy()
+
+    def gather(self, obj):
+        """Every rank's small Python object, in rank order."""
+        if self.size == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.size
+        dist.all_gather_object(out, obj)
+        return out
+
+    def raise_together(self, exc):
+        """A failure that only some ranks see (e.g. the record that kills the reference sits in one
+        range) must stop every rank, or the others wait in the next collective forever: each rank
+        reports (kind, message) or None; the first reported failure, in rank order, is raised by
+        all."""
+        kinds = {'TypeError': TypeError, 'AttributeError': AttributeError, 'NameError': NameError,
+                 'IOError': IOError, 'OSError': IOError, 'RuntimeError': RuntimeError, 'AssertionError': AssertionError}
+        mine = None if exc is None else (type(exc).__name__, str(exc))
+        for r in self.gather(mine):
+            if r is not None:
+                raise kinds.get(r[0], RuntimeError)(r[1])
 
     def close(self):
         if self._own:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.destroy_process_group()
+
+
+def check_ranges(reports, file_size):
+    """reports: per rank {'has_records', 'first_token', 'end_token'} in rank order.  The ranges tile the
+    file iff every range's end token (where the first record it does NOT own starts) is the first
+    token of the next range that has records, and the last one ends at the end of the file."""
+    prev = None
+    for r, rep in enumerate(reports):
+        if not rep['has_records']:
+            continue
+        if prev is not None and tuple(prev[1]) != tuple(rep['first_token']):
+            raise RuntimeError('byte-range decoding is inconsistent: range %d ends at %r but range %d starts at %r '
+                               '(a record-boundary guess was wrong; rerun on one GPU)'
+                               % (prev[0], tuple(prev[1]), r, tuple(rep['first_token'])))
+        prev = (r, rep['end_token'])
+    if prev is not None and tuple(prev[1]) != (file_size, 0):
+        raise RuntimeError('byte-range decoding is inconsistent: the last range ends at %r, not at the end of the file' % (tuple(prev[1]),))
+
+
+def plan_pairs(reports, rank):
+    """PE pairing across byte ranges.  The reference pairs records (2k, 2k+1) of the whole file
+    (te_count.py:78-79), so whether a range's first record is a first or a second mate depends on
+    the number of records before it.  reports: per rank {'n_records', 'first_rec'}.
+    -> (skip_first, extra_mate, unit_ordinal0): this rank pairs its records from index skip_first on;
+    if that leaves its last record alone, extra_mate (the next range's first record) completes the
+    pair, or None at the end of the file (an odd trailing record is dropped, as StopIteration does in
+    the reference)."""
+    before = sum(rep['n_records'] for rep in reports[:rank])
+    n = reports[rank]['n_records']
+    skip = before & 1 if n else 0
+    left = n - skip
+    extra = None
+    if left & 1:
+        for rep in reports[rank + 1:]:
+            if rep['n_records']:
+                extra = rep['first_rec']
+                break
+    return skip, extra, (before + skip) // 2

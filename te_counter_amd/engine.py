@@ -85,18 +85,24 @@ class Engine:
         self._check(self._lib.tec_bulk_device_buffers(self._ctx, C.byref(dc), C.byref(ds)))
         return dc.value, ds.value
 
-    def bulk_finish(self):
-        """-> (counts uint64[n_names], stats dict).  Raises NameError like the reference if a
-        read hit only 'enhancer' features (te_count.py:145-147, 258-260)."""
+    def bulk_finish(self, raise_enhancer=True):
+        """-> (counts uint64[n_names], stats dict).  A read that hit only 'enhancer' features kills the
+        reference with NameError (te_count.py:145-147, 258-260): raised here, or -- with
+        raise_enhancer=False, for callers that first have to tell the other ranks -- returned as a
+        third value."""
         counts = np.zeros(self.n_names, np.uint64)
         st = _lib.Stats()
         rc = self._lib.tec_bulk_finish(self._ctx, _ptr(counts), C.byref(st))
         self._keep = []
-        if rc == _lib.TEC_EENHANCER:
+        enhancer_only = rc == _lib.TEC_EENHANCER
+        if enhancer_only and raise_enhancer:
             raise NameError("name 'barcode' is not defined")
-        self._check(rc)
+        if not enhancer_only:
+            self._check(rc)
         stats = {k: int(getattr(st, k)) for k, _ in _lib.Stats._fields_}
-        return counts[:self._real_names], stats
+        if raise_enhancer:
+            return counts[:self._real_names], stats
+        return counts[:self._real_names], stats, enhancer_only
 
     def bulk_kernel_time(self):
         ms, nl = C.c_double(), C.c_uint64()

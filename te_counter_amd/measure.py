@@ -68,11 +68,20 @@ class measureTE:
         self._engine.upload_index(self.genome, self.bin_shift)
 
     # ------------------------------------------------------------------ bulk
-    def _open(self, filename):
+    def _open(self, filename, byte_range=None):
         if hasattr(filename, 'batches'):
             return filename
         from .bam import open_alignment
-        return open_alignment(filename, batch_size=self.batch_size)
+        return open_alignment(filename, batch_size=self.batch_size, byte_range=byte_range)
+
+    @staticmethod
+    def _decoder_for(filename):
+        """'gpu': BGZF-compressed BAM files are decoded on the device (csrc/gbam.hip); 'cpu': the host
+        decoder (csrc/bamio.hip) -- SAM text, in-memory sources, or TEC_DECODER=cpu."""
+        from .gbam import is_bgzf
+        if hasattr(filename, 'batches') or os.environ.get('TEC_DECODER', 'gpu') == 'cpu':
+            return 'cpu'
+        return 'gpu' if is_bgzf(filename) else 'cpu'
 
     def _bulk(self, filename, paired, strand, log):
         assert filename, 'You must specify a filename'
@@ -80,34 +89,33 @@ class measureTE:
             raise NotImplementedError()  # te_count.py:58-59, 183-184
         log = log or _NullLog()
         assert self.genome is not None, 'call load_genome() first'
-        src = self._open(filename)
-        tid_map = self.genome.tid_map(src.reference_names)
-        eng = self._engine
+        eng, world = self._engine, self.world
         q = self.quality_threshold
         q_int = int(q) if isinstance(q, (int, np.integer)) else None
-        n_records = 0
-        pairs = _reads.PairAssembler(tid_map, q_int or 0) if paired else None
+        n_records, failure, stats, counts = 0, None, None, None
         try:
             eng.bulk_begin(q_int or 0)
-            for ordinal, batch in enumerate(src.batches()):
-                n_records += len(batch)
-                if q_int is None and self._reaches_mapq_test(batch, paired):
-                    # `-q N` on the reference CLI hands over a list and the first record that
-                    # passes the flag filter dies in `int(mapq) < [N]` (bin/te_count:30,77;
-                    # te_count.py:88,208)
-                    raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
-                units = pairs.units(batch) if paired else _reads.se_units(batch, tid_map)
-                if not paired and (units[2] == NO_END).any():
-                    self._check_reference_end(units, q_int or 0)
-                if len(units[0]) and self.world.mine(ordinal):
-                    eng.bulk_submit(*units)
-            counts, stats = eng.bulk_finish()
-            if self.world.size > 1:  # RCCL sum-reduce of the per-GPU count vectors
-                keys = ('units', 'assigned', 'lowq', 'badchrom', 'qcfail')
-                counts, sv = self.world.sum_counts(counts, [stats[k] for k in keys])
-                stats = {k: int(v) for k, v in zip(keys, sv)}
-        finally:
-            src.close()
+            if self._decoder_for(filename) == 'gpu':
+                n_records, failure = self._bulk_gpu_decode(filename, paired, q_int or 0)
+            else:
+                n_records, failure = self._bulk_host_decode(filename, paired, q_int or 0)
+        except Exception as e:  # noqa: BLE001 -- the other ranks must hear about it before the next collective
+            if world.size == 1:
+                raise
+            failure = e
+        world.raise_together(failure)
+        counts, stats, enhancer_only = eng.bulk_finish(raise_enhancer=False)
+        keys = ('units', 'assigned', 'lowq', 'badchrom', 'qcfail')
+        if world.size > 1:  # RCCL sum-reduce of the per-GPU count vectors and log counters
+            counts, sv = world.sum_counts(counts, [stats[k] for k in keys] + [int(enhancer_only), n_records])
+            stats = {k: int(v) for k, v in zip(keys, sv)}
+            enhancer_only, n_records = bool(sv[5]), int(sv[6])
+        if q_int is None and stats['units'] - stats['qcfail'] > 0:
+            # `-q N` on the reference CLI hands over a list and the first record that passes the flag
+            # filter dies in `int(mapq) < [N]` (bin/te_count:30,77; te_count.py:88,208)
+            raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
+        if enhancer_only:  # te_count.py:145-147, 258-260 -- on every rank alike
+            raise NameError("name 'barcode' is not defined")
         units_total = n_records // 2 if paired else n_records
         self.total_reads = units_total + 1  # idx is bumped before next(sam): te_count.py:77,202 / 163,275
         self.stats = stats
@@ -119,13 +127,95 @@ class measureTE:
         log.info('{:,} Reads are QC fails'.format(stats['qcfail']))
         return {name: int(c) for name, c in zip(self.all_feature_names, counts)}
 
+    _NAME_MISMATCH = "module 'sys' has no attribute 'quit'"            # te_count.py:94 calls sys.quit()
+    _NO_END = "unsupported operand type(s) for +: 'NoneType' and 'int'"  # te_count.py:223 with reference_end None
+
+    def _bulk_gpu_decode(self, filename, paired, q):
+        """BAM file -> (this rank's byte range) -> on-GPU decode -> count kernel.  Returns (records owned
+        by this rank, the exception the reference would have died with or None)."""
+        from . import dist as _dist
+        from .bam import byte_range
+        from .gbam import NONE64, GpuBam
+        world = self.world
+        size = os.path.getsize(filename)
+        feed = GpuBam(self._engine, filename, byte_range(size, world.rank, world.size) if world.size > 1 else None)
+        self.decode_report = None
+        try:
+            tid_map = self.genome.tid_map(feed.reference_names)
+            defer = paired and world.size > 1
+            rep = feed.run_bulk(paired, q, tid_map, defer_pairing=defer)
+            self.decode_report = rep
+            failure = None
+            if not paired and rep['first_noend_live'] != NONE64:
+                failure = TypeError(self._NO_END)
+            if paired and not defer and rep['first_name_mismatch'] != NONE64:
+                failure = AttributeError(self._NAME_MISMATCH)
+            if world.size > 1:
+                reports = world.gather({k: rep[k] for k in ('n_records', 'has_records', 'first_token', 'end_token', 'first_rec')})
+                _dist.check_ranges(reports, size)
+                if paired:
+                    skip, extra, unit0 = _dist.plan_pairs(reports, world.rank)
+                    _, mism = feed.finish_pairs(q, skip, extra, unit0)
+                    if mism != NONE64:
+                        failure = AttributeError(self._NAME_MISMATCH)
+            return rep['n_records'], failure
+        finally:
+            feed.close()
+
+    def _bulk_host_decode(self, filename, paired, q):
+        """Host decoder (SAM text, in-memory record sources, TEC_DECODER=cpu): SoA batches -> units ->
+        tec_bulk_submit.  A BAM file is cut into byte ranges over the ranks like the GPU decoder does;
+        other sources are read by every rank and their batches dealt round-robin."""
+        from . import dist as _dist
+        from .gbam import is_bgzf
+        from .bam import byte_range
+        world, eng = self.world, self._engine
+        ranged = world.size > 1 and not hasattr(filename, 'batches') and is_bgzf(filename)
+        src = self._open(filename, byte_range(os.path.getsize(filename), world.rank, world.size) if ranged else None)
+        failure, n_records = None, 0
+        try:
+            tid_map = self.genome.tid_map(src.reference_names)
+            keeper = _reads.RecordKeeper() if (paired and ranged) else None
+            pairs = _reads.PairAssembler(tid_map, q) if (paired and not ranged) else None
+            for ordinal, batch in enumerate(src.batches()):
+                n_records += len(batch)
+                if keeper is not None:
+                    keeper.add(batch)
+                    continue
+                try:
+                    units = pairs.units(batch) if paired else _reads.se_units(batch, tid_map)
+                except AttributeError as e:
+                    failure = failure or e
+                    continue
+                if not paired and (units[2] == NO_END).any() and self._has_live_no_end(units, q):
+                    failure = failure or TypeError(self._NO_END)
+                if len(units[0]) and (ranged or world.mine(ordinal)):
+                    eng.bulk_submit(*units)
+            if ranged:
+                first, end, has = src.range_tokens()
+                rep = {'n_records': n_records, 'has_records': has and n_records > 0, 'first_token': first, 'end_token': end,
+                       'first_rec': keeper.record(0) if (keeper is not None and n_records) else None}
+                reports = world.gather(rep)
+                _dist.check_ranges(reports, os.path.getsize(filename))
+                if paired:
+                    skip, extra, _ = _dist.plan_pairs(reports, world.rank)
+                    try:
+                        units = keeper.units(tid_map, q, skip, extra)
+                        if len(units[0]):
+                            eng.bulk_submit(*units)
+                    except AttributeError as e:
+                        failure = failure or e
+            elif world.size > 1:
+                n_records = n_records if world.rank == 0 else 0  # every rank read the whole source: count it once
+        finally:
+            src.close()
+        return n_records, failure
+
     @staticmethod
-    def _check_reference_end(units, q):
+    def _has_live_no_end(units, q):
         # a mapped SE record without CIGAR has reference_end None: `loc2+1` dies (te_count.py:223)
         chrom, _, p2, flag, mapq = units
-        bad = (p2 == NO_END) & ((flag & _reads.FLAG_FILTER) == 0) & (mapq >= q) & (chrom >= 0)
-        if bad.any():
-            raise TypeError("unsupported operand type(s) for +: 'NoneType' and 'int'")
+        return bool(((p2 == NO_END) & ((flag & _reads.FLAG_FILTER) == 0) & (mapq >= q) & (chrom >= 0)).any())
 
     @staticmethod
     def _reaches_mapq_test(batch, paired):
@@ -164,30 +254,46 @@ class measureTE:
         with open(whitelistfilename, 'r') as fh:
             whitelist = sorted(set(line.strip() for line in fh))  # te_count.py:330-339
         self.barcodes = {}
-        src = self._open(filename)
         q = self.quality_threshold
         q_int = int(q) if isinstance(q, (int, np.integer)) else None
         log.info('Part 1: Collapsing UMI/CB combinations')
         self.load_genome()  # the reference loads it in part 3 (te_count.py:581); same index either way
         eng = self._engine
-        skip, cls_of_tid, keys = _reads.chrom_class_table(src.reference_names)
-        key_skip = np.zeros(len(keys), np.uint8)
-        for t, c in enumerate(cls_of_tid):
-            key_skip[c] = skip[t]
-        key_chrom = np.array([self.genome._chrom_lookup.get(k, -1) for k in keys], np.int32)
+        if self.world.size > 1 and self.world.rank != 0:
+            # (the single-cell path still runs on one GPU: the other ranks of a multi-GPU launch stand by)
+            self.total_reads = 0
+            return ScResult(self.all_feature_names, whitelist, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint64))
+        # --noumi and a non-int -q end in the reference's crashes: they take the host decoder, which
+        # looks at every batch on the way
+        on_gpu = self._decoder_for(filename) == 'gpu' and UMIS and q_int is not None
         n_records = 0
+        if on_gpu:
+            from .gbam import GpuBam
+            src = GpuBam(eng, filename)
+        else:
+            src = self._open(filename)
         try:
+            skip, cls_of_tid, keys = _reads.chrom_class_table(src.reference_names)
+            key_skip = np.zeros(len(keys), np.uint8)
+            for t, c in enumerate(cls_of_tid):
+                key_skip[c] = skip[t]
+            key_chrom = np.array([self.genome._chrom_lookup.get(k, -1) for k in keys], np.int32)
             eng.sc_begin(strand, q_int or 0, _reads.pack_whitelist(whitelist), self.BUNDLE_KEYS, key_chrom, key_skip)
-            for batch in src.batches(want_tags=True):
-                n_records += len(batch)
-                if q_int is None and self._reaches_mapq_test(batch, False):
-                    raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
-                arrays = _reads.sc_batch_arrays(batch, cls_of_tid)
-                if not UMIS:
-                    # --noumi: the UB|UR tags are never looked at and nothing is ever stored
-                    # (te_count.py:428-442); only the CB|CR assertion can still fire
-                    arrays = arrays[:7] + (arrays[7] | 2,)
-                eng.sc_submit(*arrays)
+            if on_gpu:
+                rep = src.run_sc(q_int, cls_of_tid)
+                self.decode_report = rep
+                n_records = rep['n_records']
+            else:
+                for batch in src.batches(want_tags=True):
+                    n_records += len(batch)
+                    if q_int is None and self._reaches_mapq_test(batch, False):
+                        raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
+                    arrays = _reads.sc_batch_arrays(batch, cls_of_tid)
+                    if not UMIS:
+                        # --noumi: the UB|UR tags are never looked at and nothing is ever stored
+                        # (te_count.py:428-442); only the CB|CR assertion can still fire
+                        arrays = arrays[:7] + (arrays[7] | 2,)
+                    eng.sc_submit(*arrays)
             ids, counts, first = eng.sc_part1()
         finally:
             src.close()

@@ -139,6 +139,46 @@ class PairAssembler:
                 raise AttributeError("module 'sys' has no attribute 'quit'")
 
 
+class RecordKeeper:
+    """PE over byte ranges on the host decoder: the records of this rank's range are kept (tid, pos,
+    flag, mapq, mate key) until the number of records in the ranges before it is known, because that
+    parity decides which records are mates (te_count.py:78-79; dist.plan_pairs)."""
+
+    def __init__(self):
+        self._parts = []
+
+    def add(self, batch):
+        if batch.qkey is None:
+            raise ValueError('byte-range pairing needs the native decoder\'s mate-name keys')
+        qk = batch.qkey
+        self._parts.append((batch.tid.copy(), batch.pos.copy(), batch.flag.copy(), batch.mapq.copy(), np.asarray(qk, np.uint64).copy()))
+
+    def _all(self):
+        if not self._parts:
+            return (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint16), np.zeros(0, np.uint8), np.zeros(0, np.uint64))
+        if len(self._parts) > 1:
+            self._parts = [tuple(np.concatenate([p[i] for p in self._parts]) for i in range(5))]
+        return self._parts[0]
+
+    def record(self, i):
+        tid, pos, flag, mapq, qk = self._all()
+        return (int(tid[i]), int(pos[i]), int(flag[i]), int(mapq[i]), int(qk[i]))
+
+    def units(self, tid_map, q, skip_first, extra_mate):
+        """Unit arrays of this range: records from index skip_first on, pairwise; extra_mate = the next
+        range's first record (tid, pos, flag, mapq, qkey), the mate of an otherwise unpaired last record."""
+        tid, pos, flag, mapq, qk = self._all()
+        if extra_mate is not None:
+            tid = np.concatenate([tid, [extra_mate[0]]]).astype(np.int32)
+            pos = np.concatenate([pos, [extra_mate[1]]]).astype(np.int32)
+            flag = np.concatenate([flag, [extra_mate[2]]]).astype(np.uint16)
+            mapq = np.concatenate([mapq, [extra_mate[3]]]).astype(np.uint8)
+            qk = np.concatenate([qk, np.array([extra_mate[4]], np.uint64)])
+        b = RecordBatch(tid[skip_first:], pos[skip_first:], np.zeros(len(tid) - skip_first, np.int32), flag[skip_first:], mapq[skip_first:])
+        b.qkey = qk[skip_first:]
+        return PairAssembler(tid_map, q).units(b)
+
+
 def chrom_class_table(reference_names):
     """--sc: per tid, (skip, class id).  skip = '_' or 'alt' in the read-side chromosome string
     (te_count.py:431-433); the class id is that string's identity (two header names that

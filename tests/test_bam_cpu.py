@@ -1,6 +1,8 @@
 """The native BGZF/BAM/SAM decoder (csrc/bamio.hip, host code) against files written by
 te_counter_amd.bam.write_bam / write_sam -- runs without a GPU."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -145,3 +147,77 @@ def test_chunked_reader_threads_and_batches(tmp_path):
     with pytest.raises(IOError):
         for _ in bam.BamSource(cut, threads=4).batches(prefetch=0):
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# vectors that were NOT produced by this repo's writer: bytes assembled from the BAM specification
+
+def _decode_all(path, want_tags=True, **kw):
+    src = bam.BamSource(str(path), **kw)
+    parts = list(src._batches(want_tags=want_tags))
+    names = src.reference_names
+    src.close()
+    if not parts:
+        z = np.zeros(0, np.int32)
+        return {'tid': z, 'pos': z, 'end': z, 'flag': z, 'mapq': z, 'tagflags': None}, names
+    out = {k: np.concatenate([getattr(b, k) for b in parts]) for k in ('tid', 'pos', 'end', 'flag', 'mapq', 'qkey')}
+    if want_tags:
+        out.update({k: np.concatenate([getattr(b, k) for b in parts]) for k in ('cb24', 'ub24', 'tagflags')})
+    return out, names
+
+
+def test_sam_spec_example_alignment(tmp_path):
+    """The example of SAMv1 section 1.1: POS / CIGAR -> the reference_end the spec's picture shows."""
+    import bamvec
+    payload, want = bamvec.spec_example()
+    p = tmp_path / 'spec.bam'
+    bamvec.write_blocks(str(p), payload, [])
+    got, names = _decode_all(p)
+    assert names == ['ref']
+    bamvec.check_rows(got, want)
+    assert len(set(got['qkey'].tolist())) == 1  # names without '/': every mate key is the empty string (te_count.py:92)
+
+
+@pytest.mark.parametrize('level', [-1, 0, 1, 6, 9])
+def test_every_cigar_op_every_aux_type_and_block_layouts(tmp_path, level):
+    """Every CIGAR op, every aux type in front of CB/UB, CR/UR fallbacks, CG:B,I, no-CIGAR and
+    reference-less CIGARs -- as one block, cut inside records (a record spanning two and three BGZF
+    blocks, a cut inside the 4-byte size field), with empty blocks in between, stored / fixed / dynamic
+    deflate blocks."""
+    import bamvec
+    payload, want, hdr_len, starts = bamvec.every_cigar_op_and_aux_type()
+    layouts = [([], ()), ([hdr_len], (0,)), ([starts[0] + 2], ()), ([starts[1] + 40, starts[1] + 90], (1,)),
+               ([starts[3] + 1, starts[5] + 3, starts[10] + 50], (0, 2)), (list(range(hdr_len, len(payload), 37)), (3, 4, 5))]
+    for cuts, empties in layouts:
+        p = tmp_path / 'zoo.bam'
+        bamvec.write_blocks(str(p), payload, cuts, level=level, empty_after=empties)
+        for threads in (1, 3):
+            got, names = _decode_all(p, threads=threads, batch_size=5)
+            assert names == ['chr1', 'chr2']
+            bamvec.check_rows(got, want)
+        # '/'-names: mates share a key, different names do not
+        assert got['qkey'][0] != got['qkey'][1]
+
+
+def test_hand_assembled_vectors_byte_ranges(tmp_path):
+    """The same records cut into 37-byte BGZF blocks and read as 1..9 byte ranges: every range owns the
+    records that start in its blocks, nothing is lost or doubled, tokens chain."""
+    import bamvec
+    from te_counter_amd import dist
+    payload, want, hdr_len, starts = bamvec.every_cigar_op_and_aux_type()
+    p = tmp_path / 'zoo.bam'
+    bamvec.write_blocks(str(p), payload, list(range(hdr_len, len(payload), 37)), level=1, empty_after=(2, 9))
+    size = os.path.getsize(str(p))
+    for world in (1, 2, 3, 5, 9):
+        rows, reports = [], []
+        for r in range(world):
+            src = bam.BamSource(str(p), byte_range=bam.byte_range(size, r, world), batch_size=4, threads=2)
+            parts = list(src._batches(want_tags=True))
+            first, end, has = src.range_tokens()
+            src.close()
+            n = sum(len(b) for b in parts)
+            reports.append({'has_records': has and n > 0, 'first_token': first, 'end_token': end, 'n_records': n})
+            rows += parts
+        got = {k: np.concatenate([getattr(b, k) for b in rows]) for k in ('tid', 'pos', 'end', 'flag', 'mapq', 'cb24', 'ub24', 'tagflags')}
+        bamvec.check_rows(got, want)
+        dist.check_ranges(reports, size)
