@@ -287,6 +287,9 @@ typedef struct tec_gbam_report {
     int odd_record_left;           /* PE, not deferred: a last unpaired record was dropped (te_count.py:78-79) */
     tec_gbam_rec first_rec, last_rec; /* PE, deferred: for the cross-range pairing */
     uint64_t blocks, blocks_redone_on_host, compressed_bytes, inflated_bytes, segment_repairs;
+    /* wall seconds of the decode loop by phase: waiting for the staging thread (pread into pinned memory),
+     * H2D + inflate kernel, segment guess / walk / chain, row extraction (+ pairing, + count kernel) */
+    double seconds_stage_wait, seconds_inflate, seconds_segments, seconds_rows;
 } tec_gbam_report;
 int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begin, uint64_t range_end, tec_gbam** out);
 void tec_gbam_close(tec_gbam* g);

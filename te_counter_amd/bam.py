@@ -166,7 +166,7 @@ def _encode_record(tid, pos, end, flag, mapq, qname, tags):
     return struct.pack('<I', len(body)) + body
 
 
-def write_bam(path, reference_names, records, reference_length=300000000):
+def write_bam(path, reference_names, records, reference_length=300000000, block_bytes=0xff00):
     """records: dicts of the schema in oracle/ref_harness.py (flag, mapq, qname, rname, pos, end, tags).
     `end` is honoured through the CIGAR (an M run plus an N gap)."""
     tid_of = {n: i for i, n in enumerate(reference_names)}
@@ -180,9 +180,9 @@ def write_bam(path, reference_names, records, reference_length=300000000):
         for r in records:
             buf += _encode_record(tid_of.get(r.get('rname'), -1), r['pos'], r['end'], r['flag'], r['mapq'],
                                   r.get('qname', 'q'), r.get('tags'))
-            while len(buf) >= 0xff00:
-                fh.write(_bgzf_block(bytes(buf[:0xff00])))
-                del buf[:0xff00]
+            while len(buf) >= block_bytes:
+                fh.write(_bgzf_block(bytes(buf[:block_bytes])))
+                del buf[:block_bytes]
         if buf:
             fh.write(_bgzf_block(bytes(buf)))
         fh.write(_BGZF_EOF)

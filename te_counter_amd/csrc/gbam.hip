@@ -30,6 +30,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -50,6 +51,8 @@ constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one
 constexpr int kInflThreads = 128;        // lanes per workgroup of the inflate kernel = lanes per CU (LDS bound)
 constexpr uint32_t kFlagFilter = TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP;
 
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct BlockDesc {
     uint32_t in_off, in_len;  // DEFLATE body inside the chunk's compressed bytes
     uint32_t out_off, isize;  // inflated bytes inside the chunk's inflated stream
@@ -57,29 +60,27 @@ struct BlockDesc {
 
 // ---- per-lane memory of the inflate kernel: tables in LDS, lane-interleaved (entry i of lane L at
 // u16 index i * 128 + L: same-i accesses of a wave are consecutive, random-i accesses always land
-// in the lane pair's own bank); code lengths and sorted symbols in global memory, interleaved per wave
+// in the lane pair's own bank); the symbols of long codes in global memory, interleaved per wave
 struct DevMem {
     uint16_t* t;
-    uint8_t* l;
     uint16_t* s;
     __device__ __forceinline__ uint32_t tab(uint32_t i) const { return t[i * kInflThreads]; }
     __device__ __forceinline__ void set_tab(uint32_t i, uint32_t v) { t[i * kInflThreads] = (uint16_t)v; }
-    __device__ __forceinline__ uint32_t len(uint32_t i) const { return l[i * 64u]; }
-    __device__ __forceinline__ void set_len(uint32_t i, uint32_t v) { l[i * 64u] = (uint8_t)v; }
     __device__ __forceinline__ uint32_t sym(uint32_t i) const { return s[i * 64u]; }
     __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
+    static __device__ __forceinline__ void store16(uint8_t* p, uint64_t lo, uint64_t hi) {
+        *reinterpret_cast<uint4*>(p) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    }
 };
 
 __global__ __launch_bounds__(kInflThreads) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
-                                                                uint8_t* lens_scr, uint16_t* syms_scr, uint32_t* n_failed,
-                                                                uint32_t* failed) {
+                                                                uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed) {
     extern __shared__ uint16_t lds_tab[];
     const uint32_t b = blockIdx.x * kInflThreads + threadIdx.x;
     if (b >= n) return;
     const size_t wave = b >> 6, lane = b & 63u;
-    DevMem m{lds_tab + threadIdx.x, lens_scr + wave * 64u * tec_ginf::kLensPerLane + lane,
-             syms_scr + wave * 64u * tec_ginf::kSymsPerLane + lane};
+    DevMem m{lds_tab + threadIdx.x, syms_scr + wave * 64u * tec_ginf::kLongSymsPerLane + lane};
     const BlockDesc d = desc[b];
     int rc = tec_ginf::kOk;
     if (d.isize) rc = tec_ginf::inflate_stream(comp + d.in_off, d.in_len, infl + d.out_off, d.isize, m);
@@ -281,7 +282,7 @@ struct tec_gbam {
     size_t chunk_bytes = 512u << 20;
     uint32_t chunk_blocks = 32768;
     // device
-    DBuf d_comp, d_desc, d_infl, d_lens, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
+    DBuf d_comp, d_desc, d_infl, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
     DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
     DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
     uint64_t r_cap = 0, u_cap = 0;
@@ -294,6 +295,7 @@ struct tec_gbam {
     bool have_first = false;
     uint64_t tok_first[2] = {0, 0}, tok_end[2] = {0, 0};
     uint64_t blocks = 0, blocks_host = 0, comp_bytes = 0, infl_bytes = 0, repairs = 0;
+    double t_stage_wait = 0, t_inflate = 0, t_segments = 0, t_rows = 0;  // seconds of the decode loop, by phase
     // deferred PE pairing
     bool deferred = false;
     uint64_t n_resident = 0;  // records kept in r_* (deferred mode), starting at row 1
@@ -334,17 +336,17 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         return;
     }
     const size_t want = (size_t)std::min<uint64_t>(g->chunk_bytes + 65536 + 64, g->file_size - off);
-    if (want + 16 > st->pinned_cap) {
+    if (want + 32 > st->pinned_cap) {
         if (st->pinned) (void)hipHostFree(st->pinned);
         st->pinned = nullptr;
         st->pinned_cap = 0;
         void* p = nullptr;
-        if (hipHostMalloc(&p, want + 16, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(&p, want + 32, hipHostMallocDefault) != hipSuccess) {
             st->error = "cannot allocate pinned staging memory";
             return;
         }
         st->pinned = static_cast<uint8_t*>(p);
-        st->pinned_cap = want + 16;
+        st->pinned_cap = want + 32;
     }
     // parallel pread: page cache -> pinned memory
     {
@@ -372,7 +374,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
                 return;
             }
     }
-    memset(st->pinned + want, 0, 16);
+    memset(st->pinned + want, 0, 32);
     size_t o = 0;
     uint64_t infl = 0;
     while (st->desc.size() < max_blocks) {
@@ -501,21 +503,20 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     G_HIP(g->d_desc.reserve((size_t)std::max(nb, 1u) * sizeof(BlockDesc)));
     G_HIP(g->d_infl.reserve(kCarryMax + st->inflated + 256, true, kCarryMax));  // keep: the carry sits below kCarryMax
     const uint32_t waves = (nb + 63u) / 64u;
-    G_HIP(g->d_lens.reserve((size_t)std::max(waves, 1u) * 64u * tec_ginf::kLensPerLane));
-    G_HIP(g->d_syms.reserve((size_t)std::max(waves, 1u) * 64u * tec_ginf::kSymsPerLane * 2));
+    G_HIP(g->d_syms.reserve((size_t)std::max(waves, 1u) * 64u * tec_ginf::kLongSymsPerLane * 2));
     G_HIP(g->d_ctl.reserve(64 + (size_t)std::max(nb, 1u) * 4));
     uint32_t* d_nfailed = g->d_ctl.as<uint32_t>();
     uint32_t* d_failed = d_nfailed + 16;
     uint8_t* d_stream_base = g->d_infl.as<uint8_t>() + kCarryMax;  // inflated bytes of this chunk start here
     uint8_t* d_stream = d_stream_base - carry;                     // stream offset 0
+    double t0 = now_s();
     if (nb) {
-        G_HIP(hipMemcpyAsync(g->d_comp.p, st->pinned, st->bytes + 8, hipMemcpyHostToDevice, cs));
+        G_HIP(hipMemcpyAsync(g->d_comp.p, st->pinned, st->bytes + tec_ginf::kInPad, hipMemcpyHostToDevice, cs));
         G_HIP(hipMemcpyAsync(g->d_desc.p, st->desc.data(), (size_t)nb * sizeof(BlockDesc), hipMemcpyHostToDevice, cs));
         G_HIP(hipMemsetAsync(d_nfailed, 0, 64, cs));
         hipLaunchKernelGGL(ginflate_kernel, dim3((nb + kInflThreads - 1) / kInflThreads), dim3(kInflThreads),
                            (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, cs, g->d_desc.as<BlockDesc>(), nb,
-                           g->d_comp.as<uint8_t>(), d_stream_base, g->d_lens.as<uint8_t>(), g->d_syms.as<uint16_t>(), d_nfailed,
-                           d_failed);
+                           g->d_comp.as<uint8_t>(), d_stream_base, g->d_syms.as<uint16_t>(), d_nfailed, d_failed);
         G_HIP(hipGetLastError());
         uint32_t n_failed = 0;
         G_HIP(hipMemcpyAsync(&n_failed, d_nfailed, 4, hipMemcpyDeviceToHost, cs));
@@ -536,6 +537,8 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
         g->comp_bytes += st->bytes;
         g->infl_bytes += st->inflated;
     }
+    g->t_inflate += now_s() - t0;
+    t0 = now_s();
     // ---- segments
     const uint32_t n_seg = (total + kSeg - 1) >> kSegShift;
     G_HIP(g->d_guess.reserve((size_t)n_seg * 4));
@@ -609,6 +612,8 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     }
     res->n_records = n_rec;
     res->tail = tail;
+    g->t_segments += now_s() - t0;
+    t0 = now_s();
     if (!n_rec) return TEC_OK;
     // ---- rows of the record arrays
     uint64_t slot0;
@@ -663,6 +668,8 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
             rs->have_odd = false;
         }
     }
+    G_HIP(hipStreamSynchronize(cs));
+    g->t_rows += now_s() - t0;
     return TEC_OK;
 }
 
@@ -776,7 +783,7 @@ extern "C" void tec_gbam_close(tec_gbam* g) {
         (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->s_compute);
     }
-    for (DBuf* b : {&g->d_comp, &g->d_desc, &g->d_infl, &g->d_lens, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land,
+    for (DBuf* b : {&g->d_comp, &g->d_desc, &g->d_infl, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land,
                     &g->d_offs, &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
                     &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
         b->release();
@@ -857,8 +864,10 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     bool first_token_pending = !g->start_known;
     for (;;) {
         {
+            const double tw = now_s();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return ready[slot] == 1; });
+            g->t_stage_wait += now_s() - tw;
         }
         Staged* st = &g->slots[slot];
         if (!st->error.empty()) {
@@ -1005,6 +1014,10 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
         rep->compressed_bytes = g->comp_bytes;
         rep->inflated_bytes = g->infl_bytes;
         rep->segment_repairs = g->repairs;
+        rep->seconds_stage_wait = g->t_stage_wait;
+        rep->seconds_inflate = g->t_inflate;
+        rep->seconds_segments = g->t_segments;
+        rep->seconds_rows = g->t_rows;
         rep->units_counted = rs.units_done;
         rep->odd_record_left = rs.have_odd ? 1 : 0;
         if (a.mode == kModePE && a.deferred && g->n_resident) {

@@ -2,14 +2,21 @@
 // (gbam.hip), written so that the very same source also compiles for the host, where the CPU test
 // suite runs it against zlib on every stream shape zlib can produce.
 //
-// Why a different decoder from inflate_fast.h: on the GPU one lane inflates one BGZF block, and what
-// limits the number of lanes per CU is table memory.  Tables are therefore small and 16-bit:
-//   literal/length  9-bit first level (512 x u16), distance 6-bit first level (64 x u16)
-//   = 1152 bytes per lane -> 128 lanes per CU in 144 KiB of LDS.
-// Codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit, from
-// per-length counts kept in registers (packed) and a sorted symbol list in the lane's scratch memory.
-// Base values and extra-bit counts of length / distance symbols are computed arithmetically instead
-// of being looked up.
+// Why a different decoder from inflate_fast.h: on the GPU one lane inflates one BGZF block, what limits
+// the number of lanes per CU is table memory, and what limits a lane's speed is the number of
+// global-memory round trips on its critical path (on gfx9 loads and stores retire in order through one
+// counter, so a load that follows a store waits for that store).  Hence:
+//   * tables are small and 16-bit, in LDS: literal/length 9-bit first level (512 entries), distance
+//     6-bit (64) -- plus 16 spare entries = 1184 bytes per lane -> 128 lanes per CU in 148 KiB;
+//   * the code lengths of a dynamic block are kept as nibbles in the (not yet built) distance-table
+//     area, so that building the tables touches LDS and registers only;
+//   * codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit,
+//     from per-length counts packed in registers; only their symbols live in global scratch;
+//   * base values and extra-bit counts of length / distance symbols are computed arithmetically;
+//   * output goes through a 16-byte register accumulator and leaves as aligned 16-byte stores; the
+//     last 32-47 bytes stay addressable in registers, so matches at distance <= 32 (runs, short
+//     periods) never read memory, and farther matches read memory that is certainly written;
+//   * input arrives as 8-byte loads issued one step ahead of their use.
 //
 // Replaces, on the device, the BGZF inflation that the reference gets from pysam / htslib
 // (te_count/te_count.py:65,190,351); follows RFC 1951 only.
@@ -31,26 +38,55 @@ constexpr int kLitRoot = 9;
 constexpr int kDistRoot = 6;
 constexpr uint32_t kLitEntries = 1u << kLitRoot;
 constexpr uint32_t kDistEntries = 1u << kDistRoot;
-constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries;  // u16 each: 1152 bytes
-constexpr uint32_t kLensPerLane = 320;                            // code-length scratch (bytes)
-constexpr uint32_t kSymsPerLane = 320;                            // sorted symbols: 288 literal/length + 32 distance (u16)
+constexpr uint32_t kLenArea = kLitEntries;                            // nibble store of the code lengths: entries [512, 592)
+constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries + 16u;  // u16 each: 1184 bytes
+constexpr uint32_t kLongSymsPerLane = 320;                            // symbols of codes longer than the first level (u16, global)
+constexpr uint32_t kInPad = 16;                                       // readable bytes the caller guarantees behind the input
 
 // Reasons a block is handed back to the host's referee decoder (zlib / inflate_fast.h).
 enum : int { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadCode = 4, kBadSymbol = 5, kBadDistance = 6,
              kOutputOverrun = 7, kInputOverrun = 8, kShortOutput = 9 };
 
+// Per-lane memory.  The device instantiation keeps `tab` in LDS and the long-code symbols in global
+// memory; the host instantiation uses plain arrays.
+//   uint32_t tab(uint32_t i) / void set_tab(uint32_t i, uint32_t v)     i < kEntriesPerLane
+//   uint32_t sym(uint32_t i) / void set_sym(uint32_t i, uint32_t v)     i < kLongSymsPerLane
+//   void store16(uint8_t* aligned16, uint64_t lo, uint64_t hi)
+struct HostMem {
+    uint16_t t[kEntriesPerLane];
+    uint16_t s[kLongSymsPerLane];
+    uint32_t tab(uint32_t i) const { return t[i]; }
+    void set_tab(uint32_t i, uint32_t v) { t[i] = (uint16_t)v; }
+    uint32_t sym(uint32_t i) const { return s[i]; }
+    void set_sym(uint32_t i, uint32_t v) { s[i] = (uint16_t)v; }
+    static void store16(uint8_t* p, uint64_t lo, uint64_t hi) {
+        memcpy(p, &lo, 8);
+        memcpy(p + 8, &hi, 8);
+    }
+};
+
+// Code lengths as nibbles in table entries [kLenArea, kLenArea + 80): four per 16-bit entry.
+template <class Mem>
+TEC_HD uint32_t len_get(const Mem& m, uint32_t i) { return (m.tab(kLenArea + (i >> 2)) >> (4u * (i & 3u))) & 15u; }
+template <class Mem>
+TEC_HD void len_set(Mem& m, uint32_t i, uint32_t v) {
+    const uint32_t e = kLenArea + (i >> 2), sh = 4u * (i & 3u);
+    m.set_tab(e, (m.tab(e) & ~(15u << sh)) | (v << sh));
+}
+
 // Counts of codes per length, 12 bits each, five lengths per 64-bit word (lengths 1..15).
 struct Counts {
     uint64_t w[3];
     TEC_HD void clear() { w[0] = w[1] = w[2] = 0; }
-    TEC_HD void add(uint32_t len) {  // len 1..15
+    TEC_HD void add_n(uint32_t len, uint32_t n) {  // len 1..15
         const uint32_t k = len - 1u;
-        const uint64_t one = 1ull << (12u * (k % 5u));
+        const uint64_t v = (uint64_t)n << (12u * (k % 5u));
         const uint32_t q = k / 5u;
-        w[0] += q == 0 ? one : 0ull;
-        w[1] += q == 1 ? one : 0ull;
-        w[2] += q == 2 ? one : 0ull;
+        w[0] += q == 0 ? v : 0ull;
+        w[1] += q == 1 ? v : 0ull;
+        w[2] += q == 2 ? v : 0ull;
     }
+    TEC_HD void add(uint32_t len) { add_n(len, 1u); }
     TEC_HD uint32_t get(uint32_t len) const {
         const uint32_t k = len - 1u;
         const uint32_t q = k / 5u;
@@ -59,46 +95,73 @@ struct Counts {
     }
 };
 
+// Next canonical code per length, 16 bits each, four lengths per 64-bit word.
+struct NextCodes {
+    uint64_t w[4];
+    TEC_HD void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+    TEC_HD void set(uint32_t len, uint32_t v) {
+        const uint32_t q = len >> 2, sh = 16u * (len & 3u);
+        const uint64_t mask = ~(0xFFFFull << sh), val = (uint64_t)(v & 0xFFFFu) << sh;
+        w[0] = q == 0 ? (w[0] & mask) | val : w[0];
+        w[1] = q == 1 ? (w[1] & mask) | val : w[1];
+        w[2] = q == 2 ? (w[2] & mask) | val : w[2];
+        w[3] = q == 3 ? (w[3] & mask) | val : w[3];
+    }
+    TEC_HD uint32_t take(uint32_t len) {  // returns the code and advances it
+        const uint32_t q = len >> 2, sh = 16u * (len & 3u);
+        const uint64_t v = q == 0 ? w[0] : (q == 1 ? w[1] : (q == 2 ? w[2] : w[3]));
+        const uint64_t one = 1ull << sh;
+        w[0] += q == 0 ? one : 0ull;
+        w[1] += q == 1 ? one : 0ull;
+        w[2] += q == 2 ? one : 0ull;
+        w[3] += q == 3 ? one : 0ull;
+        return (uint32_t)(v >> sh) & 0xFFFFu;
+    }
+};
+
 // What the canonical (bit by bit) decoder of codes longer than the first level needs.
 struct LongCodes {
     Counts counts;
     uint32_t first;  // first code of length root+1, i.e. puff's `first` after the iteration len = root
-    uint32_t index;  // number of symbols with length <= root
 };
 
-// Per-lane memory.  The device instantiation keeps `tab` in LDS and the two scratch arrays in global
-// memory, lane-interleaved; the host instantiation uses plain arrays.
-//   uint32_t tab(uint32_t i) / void set_tab(uint32_t i, uint32_t v)     i < kEntriesPerLane
-//   uint32_t len(uint32_t i) / void set_len(uint32_t i, uint32_t v)     i < kLensPerLane
-//   uint32_t sym(uint32_t i) / void set_sym(uint32_t i, uint32_t v)     i < kSymsPerLane
-struct HostMem {
-    uint16_t t[kEntriesPerLane];
-    uint8_t l[kLensPerLane];
-    uint16_t s[kSymsPerLane];
-    uint32_t tab(uint32_t i) const { return t[i]; }
-    void set_tab(uint32_t i, uint32_t v) { t[i] = (uint16_t)v; }
-    uint32_t len(uint32_t i) const { return l[i]; }
-    void set_len(uint32_t i, uint32_t v) { l[i] = (uint8_t)v; }
-    uint32_t sym(uint32_t i) const { return s[i]; }
-    void set_sym(uint32_t i, uint32_t v) { s[i] = (uint16_t)v; }
-};
-
+// Input: 64-bit bit buffer fed 32 bits at a time from a two-deep queue of 8-byte loads (the load of
+// the word after next is in flight while the current one is consumed).
 struct BitReader {
-    const uint8_t* ip;
     const uint8_t* in;
     const uint8_t* in_end;
-    uint64_t buf;
-    uint32_t cnt;
-    // At least 32 valid bits afterwards.  Never reads beyond in_end + 4 (the caller pads its buffers
-    // by four bytes): past the end the last word is fed again, ip keeps counting, and overrun() /
-    // the ip checks of the caller reject the stream.
-    TEC_HD void refill() {
+    const uint8_t* lp;  // address of the next 8-byte load
+    uint64_t buf, cur, nxt;
+    uint32_t cnt;       // valid bits in buf
+    uint32_t cur_left;  // bytes of `cur` not yet moved into buf (8, 4 or 0)
+    uint32_t taken;     // bytes of the stream moved into buf so far
+    TEC_HD uint64_t load8() {
+        uint64_t v;
+        memcpy(&v, lp < in_end ? lp : in_end, 8);  // never beyond in_end + 8
+        lp += 8;
+        return v;
+    }
+    TEC_HD void start(const uint8_t* from) {
+        lp = from;
+        buf = 0;
+        cnt = 0;
+        cur = load8();
+        nxt = load8();
+        cur_left = 8;
+        taken = (uint32_t)(from - in);
+    }
+    TEC_HD void refill() {  // at least 32 valid bits afterwards
         if (cnt <= 32u) {
-            uint32_t v;
-            memcpy(&v, ip < in_end ? ip : in_end, 4);
-            buf |= (uint64_t)v << cnt;
-            ip += 4;
+            if (cur_left == 0u) {
+                cur = nxt;
+                nxt = load8();
+                cur_left = 8;
+            }
+            buf |= (cur & 0xFFFFFFFFull) << cnt;
+            cur >>= 32;
+            cur_left -= 4u;
             cnt += 32u;
+            taken += 4u;
         }
     }
     TEC_HD uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
@@ -111,18 +174,72 @@ struct BitReader {
         drop(n);
         return v;
     }
-    // bits consumed so far beyond the end of the input (> 0: the stream is truncated)
-    TEC_HD bool overrun() const { return (int64_t)(ip - in) * 8 - (int64_t)cnt > (int64_t)(in_end - in) * 8; }
+    // stream position (bytes) of the first bit that has not been consumed, rounded down
+    TEC_HD uint32_t byte_pos() const { return taken - (cnt >> 3); }
+    TEC_HD bool overrun() const { return (uint64_t)taken * 8u - cnt > (uint64_t)(in_end - in) * 8u; }
+    TEC_HD bool far_overrun() const { return taken > (uint32_t)(in_end - in) + 16u; }
+};
+
+// Output: bytes collect in a 16-byte group that maps onto a 16-byte ALIGNED window of the output
+// address space; a completed group leaves as one aligned store.  The two groups before it stay in
+// registers: together with the current one they answer every read at distance <= 32.
+template <class Mem>
+struct OutAcc {
+    uint8_t* out;
+    uint32_t out_len, op, mis;  // mis = address of out modulo 16
+    uint64_t c_lo, c_hi, p_lo, p_hi, q_lo, q_hi;  // current, previous, the one before
+    TEC_HD void start(uint8_t* o, uint32_t n) {
+        out = o;
+        out_len = n;
+        op = 0;
+        mis = (uint32_t)((uintptr_t)o & 15u);
+        c_lo = c_hi = p_lo = p_hi = q_lo = q_hi = 0;
+    }
+    static TEC_HD uint8_t byte_of(uint64_t lo, uint64_t hi, uint32_t j) { return (uint8_t)((j < 8u ? lo : hi) >> (8u * (j & 7u))); }
+    TEC_HD void put(uint32_t b) {  // caller checked op < out_len
+        const uint32_t k = (op + mis) & 15u;
+        const uint64_t v = (uint64_t)(b & 255u) << (8u * (k & 7u));
+        c_lo |= k < 8u ? v : 0ull;
+        c_hi |= k < 8u ? 0ull : v;
+        ++op;
+        if (k == 15u) {
+            if (op >= 16u) {
+                Mem::store16(out + (op - 16u), c_lo, c_hi);
+            } else {  // the block's first group starts before `out`: only its own bytes may be written
+                for (uint32_t j = 16u - op; j < 16u; ++j) out[j - (16u - op)] = byte_of(c_lo, c_hi, j);
+            }
+            q_lo = p_lo;
+            q_hi = p_hi;
+            p_lo = c_lo;
+            p_hi = c_hi;
+            c_lo = c_hi = 0;
+        }
+    }
+    // the byte written d positions ago, 1 <= d <= 32 (and d <= op)
+    TEC_HD uint32_t back(uint32_t d) const {
+        const uint32_t k = (op + mis) & 15u;       // bytes in the current group
+        const uint32_t j = (k + 48u - d) & 15u;    // position inside its group
+        const uint32_t g = d <= k ? 0u : (d <= k + 16u ? 1u : 2u);
+        const uint64_t lo = g == 0u ? c_lo : (g == 1u ? p_lo : q_lo);
+        const uint64_t hi = g == 0u ? c_hi : (g == 1u ? p_hi : q_hi);
+        return byte_of(lo, hi, j);
+    }
+    // the unfinished last group
+    TEC_HD void finish() {
+        const uint32_t k = (op + mis) & 15u;
+        const uint32_t own = k < op ? k : op;  // bytes of the group that belong to this block
+        for (uint32_t j = 0; j < own; ++j) out[op - own + j] = byte_of(c_lo, c_hi, k - own + j);
+    }
 };
 
 TEC_HD uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32u - len); }
 
 // Canonical Huffman tables of one code (RFC 1951 3.2.2).  lens(i), i < n: code lengths.  Entries
 // [tab_base, tab_base + 2^root): (symbol << 4) | length for codes of at most `root` bits, 0 for
-// prefixes of longer codes and for unused patterns.  sym_base: where the symbols sorted by (length,
-// value) go (needed by the long-code decoder).  Returns false for an over-subscribed code or an
-// incomplete one that zlib would refuse (inftrees.c: incomplete is allowed only for no code at all,
-// or for a literal/length or distance code that consists of a single one-bit code).
+// prefixes of longer codes and for unused patterns.  Symbols of longer codes go, sorted by (length,
+// value), to the lane's global list from sym_base on.  Returns false for an over-subscribed code or
+// an incomplete one that zlib would refuse (inftrees.c: incomplete is allowed only for no code at
+// all, or for a literal/length or distance code that consists of a single one-bit code).
 template <class Mem, class LenFn>
 TEC_HD bool build_tables(Mem& m, LenFn lens, uint32_t n, uint32_t root, uint32_t tab_base, uint32_t sym_base, bool is_cl,
                          LongCodes* lc) {
@@ -132,53 +249,38 @@ TEC_HD bool build_tables(Mem& m, LenFn lens, uint32_t n, uint32_t root, uint32_t
         const uint32_t l = lens(i);
         if (l) cnt.add(l);
     }
-    // completeness, offsets of every length in the sorted symbol list
     int32_t left = 1;
-    uint32_t max_len = 0, total = 0;
-    Counts offs;  // running offsets (<= 320: fits 12 bits)
-    offs.clear();
+    uint32_t max_len = 0, code = 0, n_long = 0;
+    NextCodes next;
+    next.clear();
+    Counts long_offs;  // where the symbols of each length > root start in the lane's long-symbol list
+    long_offs.clear();
+    lc->counts = cnt;
+    lc->first = 0;
     for (uint32_t l = 1; l <= 15u; ++l) {
         const uint32_t c = cnt.get(l);
         left = (left << 1) - (int32_t)c;
         if (left < 0) return false;
         if (c) max_len = l;
-        // offs[l] = total: add `total` into slot l
-        const uint32_t k = l - 1u, q = k / 5u;
-        const uint64_t add = (uint64_t)total << (12u * (k % 5u));
-        offs.w[0] += q == 0 ? add : 0ull;
-        offs.w[1] += q == 1 ? add : 0ull;
-        offs.w[2] += q == 2 ? add : 0ull;
-        total += c;
+        next.set(l, code);
+        code = (code + c) << 1;
+        if (l == root) lc->first = code;  // first code of length root + 1
+        if (l > root) {
+            long_offs.add_n(l, n_long);
+            n_long += c;
+        }
     }
     if (left > 0 && max_len > 0 && (is_cl || max_len != 1u)) return false;
-    // symbols sorted by (length, value)
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t l = lens(i);
-        if (!l) continue;
-        m.set_sym(sym_base + offs.get(l), i);
-        offs.add(l);
-    }
     for (uint32_t i = 0; i < (1u << root); ++i) m.set_tab(tab_base + i, 0u);
-    // codes in canonical order: within a length consecutive, (code + count) << 1 between lengths
-    uint32_t code = 0, idx = 0;
-    lc->counts = cnt;
-    lc->first = 0;
-    lc->index = 0;
-    for (uint32_t l = 1; l <= 15u; ++l) {
-        const uint32_t c = cnt.get(l);
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t l = lens(s);
+        if (!l) continue;
         if (l <= root) {
-            for (uint32_t j = 0; j < c; ++j) {
-                const uint32_t s = m.sym(sym_base + idx + j);
-                const uint32_t e = (s << 4) | l;
-                for (uint32_t x = bitrev(code + j, l); x < (1u << root); x += 1u << l) m.set_tab(tab_base + x, e);
-            }
-        }
-        // (codes longer than root leave their first-level entries 0: the long-code path)
-        code = (code + c) << 1;
-        idx += c;
-        if (l == root) {
-            lc->first = code;  // first code of length root + 1
-            lc->index = idx;
+            const uint32_t e = (s << 4) | l;
+            for (uint32_t x = bitrev(next.take(l), l); x < (1u << root); x += 1u << l) m.set_tab(tab_base + x, e);
+        } else {  // first-level entries of its prefix stay 0: the long-code path
+            m.set_sym(sym_base + long_offs.get(l), s);
+            long_offs.add(l);
         }
     }
     return true;
@@ -190,7 +292,8 @@ template <class Mem>
 TEC_HD uint32_t decode_long(const Mem& m, BitReader& br, uint32_t root, uint32_t sym_base, const LongCodes& lc) {
     uint32_t code = bitrev(br.peek(root), root) << 1;
     br.drop(root);
-    uint32_t first = lc.first, index = lc.index;
+    uint32_t first = lc.first, index = 0;
+#pragma unroll 1
     for (uint32_t l = root + 1u; l <= 15u; ++l) {
         code |= br.peek(1);
         br.drop(1);
@@ -204,11 +307,15 @@ TEC_HD uint32_t decode_long(const Mem& m, BitReader& br, uint32_t root, uint32_t
 }
 
 // Inflates the raw DEFLATE stream in[0, in_len) into exactly out_len bytes.  kOk, or the reason the
-// block must be redone by the referee.  `in` must be readable up to in + in_len + 4.
+// block must be redone by the referee.  `in` must be readable up to in + in_len + kInPad.
 template <class Mem>
 TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, Mem& m) {
-    BitReader br{in, in, in + in_len, 0ull, 0u};
-    uint32_t op = 0;
+    BitReader br;
+    br.in = in;
+    br.in_end = in + in_len;
+    br.start(in);
+    OutAcc<Mem> oa;
+    oa.start(out, out_len);
     bool last = false;
     while (!last) {
         br.refill();
@@ -222,21 +329,25 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             br.refill();
             const uint32_t nlen = br.get(16);
             if ((len ^ nlen) != 0xFFFFu) return kBadStored;
-            // whole bytes still in the bit buffer belong to the payload: step back to them
-            br.ip -= br.cnt >> 3;
-            br.buf = 0;
-            br.cnt = 0;
-            if ((uint32_t)(br.in_end - br.ip) < len) return kInputOverrun;
-            if (out_len - op < len) return kOutputOverrun;
-            for (uint32_t k = 0; k < len; ++k) out[op + k] = br.ip[k];
-            br.ip += len;
-            op += len;
+            const uint32_t pos = br.byte_pos();  // whole bytes still in the bit buffer belong to the payload
+            if (pos > in_len || in_len - pos < len) return kInputOverrun;
+            if (out_len - oa.op < len) return kOutputOverrun;
+            const uint8_t* src = in + pos;
+            uint32_t k = 0;
+            for (; k + 8u <= len; k += 8u) {
+                uint64_t v;
+                memcpy(&v, src + k, 8);
+                for (uint32_t j = 0; j < 8u; ++j) oa.put((uint32_t)(v >> (8u * j)));
+            }
+            for (; k < len; ++k) oa.put(src[k]);
+            br.start(src + len);
             continue;
         }
         uint32_t hlit = 288, hdist = 32;
         if (type == 1u) {  // fixed codes (RFC 1951 3.2.6)
-            for (uint32_t i = 0; i < 288u; ++i) m.set_len(i, i < 144u ? 8u : (i < 256u ? 9u : (i < 280u ? 7u : 8u)));
-            for (uint32_t i = 0; i < 32u; ++i) m.set_len(288u + i, 5u);
+            for (uint32_t i = 0; i < 80u; ++i) m.set_tab(kLenArea + i, 0u);
+            for (uint32_t i = 0; i < 288u; ++i) len_set(m, i, i < 144u ? 8u : (i < 256u ? 9u : (i < 280u ? 7u : 8u)));
+            for (uint32_t i = 0; i < 32u; ++i) len_set(m, 288u + i, 5u);
         } else {  // dynamic codes: the code-length code first (3.2.7)
             br.refill();
             hlit = br.get(5) + 257u;
@@ -255,9 +366,10 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 cl |= (uint64_t)br.get(3) << (3u * s);
             }
             LongCodes unused;
-            // 7-bit table in the (not yet built) literal/length area; its symbol list goes to the tail of the scratch
-            if (!build_tables(m, [&](uint32_t i) { return (uint32_t)(cl >> (3u * i)) & 7u; }, 19u, 7u, 0u, 288u, true, &unused))
+            // its 7-bit table sits in the (not yet built) literal/length area; no code is longer than 7 bits
+            if (!build_tables(m, [&](uint32_t i) { return (uint32_t)(cl >> (3u * i)) & 7u; }, 19u, 7u, 0u, 0u, true, &unused))
                 return kBadCodeLengths;
+            for (uint32_t i = 0; i < 80u; ++i) m.set_tab(kLenArea + i, 0u);
             uint32_t i = 0, prev = 0;
             const uint32_t want = hlit + hdist;
             while (i < want) {
@@ -267,7 +379,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 br.drop(e & 15u);
                 const uint32_t s = e >> 4;
                 if (s < 16u) {
-                    m.set_len(i++, s);
+                    len_set(m, i++, s);
                     prev = s;
                 } else {
                     uint32_t rep, v = 0;
@@ -281,17 +393,26 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                         rep = 11u + br.get(7);
                     }
                     if (i + rep > want) return kBadCodeLengths;
-                    for (uint32_t k = 0; k < rep; ++k) m.set_len(i + k, v);
+                    if (v)
+                        for (uint32_t k = 0; k < rep; ++k) len_set(m, i + k, v);
                     i += rep;
                     prev = v;
                 }
             }
             if (br.overrun()) return kInputOverrun;
-            if (m.len(256) == 0u) return kBadCodeLengths;  // no end-of-block code
+            if (len_get(m, 256) == 0u) return kBadCodeLengths;  // no end-of-block code
+        }
+        // the distance code lengths move to registers (<= 32 x 4 bits): their table is built over the nibble store
+        uint64_t dl_lo = 0, dl_hi = 0;
+        for (uint32_t i = 0; i < hdist; ++i) {
+            const uint64_t v = (uint64_t)len_get(m, hlit + i) << (4u * (i & 15u));
+            dl_lo |= i < 16u ? v : 0ull;
+            dl_hi |= i < 16u ? 0ull : v;
         }
         LongCodes ll, ld;
-        if (!build_tables(m, [&](uint32_t i) { return m.len(i); }, hlit, (uint32_t)kLitRoot, 0u, 0u, false, &ll)) return kBadCode;
-        if (!build_tables(m, [&](uint32_t i) { return m.len(hlit + i); }, hdist, (uint32_t)kDistRoot, kLitEntries, 288u, false, &ld))
+        if (!build_tables(m, [&](uint32_t i) { return len_get(m, i); }, hlit, (uint32_t)kLitRoot, 0u, 0u, false, &ll)) return kBadCode;
+        if (!build_tables(m, [&](uint32_t i) { return (uint32_t)((i < 16u ? dl_lo : dl_hi) >> (4u * (i & 15u))) & 15u; }, hdist,
+                          (uint32_t)kDistRoot, kLitEntries, 288u, false, &ld))
             return kBadCode;
         // ---- the block's symbols
         for (;;) {
@@ -306,8 +427,8 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 if (s == 0xFFFFu) return kBadSymbol;
             }
             if (s < 256u) {
-                if (op >= out_len) return kOutputOverrun;
-                out[op++] = (uint8_t)s;
+                if (oa.op >= out_len) return kOutputOverrun;
+                oa.put(s);
                 continue;
             }
             if (s == 256u) break;
@@ -333,33 +454,35 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             uint32_t dist = d < 4u ? 1u + d : 1u + ((2u + (d & 1u)) << dx);
             br.refill();
             dist += br.get(dx);
-            if (dist > op) return kBadDistance;
-            if (out_len - op < length) return kOutputOverrun;
-            if (br.ip > br.in_end + 8) return kInputOverrun;
-            uint8_t* q = out + op;
-            const uint8_t* p = q - dist;
-            op += length;
+            if (dist > oa.op) return kBadDistance;
+            if (out_len - oa.op < length) return kOutputOverrun;
+            if (br.far_overrun()) return kInputOverrun;
             if (dist == 1u) {  // a run of one byte (quality strings)
-                const uint8_t v = *p;
-                for (uint32_t k = 0; k < length; ++k) q[k] = v;
-            } else if (dist >= 4u) {  // four source bytes are never bytes this match writes within the same group
+                const uint32_t v = oa.back(1);
+                for (uint32_t k = 0; k < length; ++k) oa.put(v);
+            } else if (dist <= 32u) {  // the source is still in registers
+                for (uint32_t k = 0; k < length; ++k) oa.put(oa.back(dist));
+            } else {  // the source was stored at least one whole group ago
                 uint32_t k = 0;
-                for (; k + 4u <= length; k += 4u) {
-                    const uint8_t a = p[k], b = p[k + 1], c = p[k + 2], e4 = p[k + 3];
-                    q[k] = a;
-                    q[k + 1] = b;
-                    q[k + 2] = c;
-                    q[k + 3] = e4;
+                for (; k + 8u <= length; k += 8u) {
+                    uint64_t v;
+                    memcpy(&v, oa.out + (oa.op - dist), 8);
+                    for (uint32_t j = 0; j < 8u; ++j) oa.put((uint32_t)(v >> (8u * j)));
                 }
-                for (; k < length; ++k) q[k] = p[k];
-            } else {
-                for (uint32_t k = 0; k < length; ++k) q[k] = p[k];
+                if (k < length) {
+                    uint64_t v = 0;
+                    const uint8_t* p = oa.out + (oa.op - dist);
+                    for (uint32_t j = 0; j < length - k; ++j) v |= (uint64_t)p[j] << (8u * j);
+                    for (uint32_t j = 0; k < length; ++k, ++j) oa.put((uint32_t)(v >> (8u * j)));
+                }
             }
         }
-        if (br.ip > br.in_end + 8) return kInputOverrun;
+        if (br.far_overrun()) return kInputOverrun;
     }
     if (br.overrun()) return kInputOverrun;
-    return op == out_len ? kOk : kShortOutput;
+    if (oa.op != out_len) return kShortOutput;
+    oa.finish();
+    return kOk;
 }
 
 }  // namespace tec_ginf

@@ -30,7 +30,8 @@ class GbamReport(C.Structure):
                 ('end_token', C.c_uint64 * 2), ('first_noend_live', C.c_uint64), ('first_name_mismatch', C.c_uint64),
                 ('units_counted', C.c_uint64), ('odd_record_left', C.c_int), ('first_rec', GbamRec), ('last_rec', GbamRec),
                 ('blocks', C.c_uint64), ('blocks_redone_on_host', C.c_uint64), ('compressed_bytes', C.c_uint64),
-                ('inflated_bytes', C.c_uint64), ('segment_repairs', C.c_uint64)]
+                ('inflated_bytes', C.c_uint64), ('segment_repairs', C.c_uint64), ('seconds_stage_wait', C.c_double),
+                ('seconds_inflate', C.c_double), ('seconds_segments', C.c_double), ('seconds_rows', C.c_double)]
 
     def as_dict(self):
         return {'n_records': int(self.n_records), 'has_records': bool(self.has_records),
@@ -41,7 +42,9 @@ class GbamReport(C.Structure):
                 'first_rec': self.first_rec.as_tuple(), 'last_rec': self.last_rec.as_tuple(),
                 'blocks': int(self.blocks), 'blocks_redone_on_host': int(self.blocks_redone_on_host),
                 'compressed_bytes': int(self.compressed_bytes), 'inflated_bytes': int(self.inflated_bytes),
-                'segment_repairs': int(self.segment_repairs)}
+                'segment_repairs': int(self.segment_repairs),
+                'seconds': {'stage_wait': round(self.seconds_stage_wait, 4), 'inflate': round(self.seconds_inflate, 4),
+                            'segments': round(self.seconds_segments, 4), 'rows': round(self.seconds_rows, 4)}}
 
 
 def is_bgzf(path):
