@@ -9,6 +9,16 @@ A step is one pass of the count kernel over one HBM-resident batch of synthetic 
 replica (weak scaling); the timed region ends with the RCCL sum-reduce of the count vector and
 the copy of counts + stats to the host, i.e. it is a complete counting job.  One JSON line on
 rank 0.
+
+At N = 1 the line also carries what a user of te_count sees, all measured in this run:
+  cpu_baseline              the pure-Python restatement of the reference loop on a bounded sample
+  cpu_baseline_c_1core      the C restatement, one core
+  cpu_baseline_c_allcores   the same, threads over disjoint unit ranges
+  pcie_inclusive            pinned host batches -> hipMemcpyAsync -> kernel
+  end_to_end_from_bam       a synthetic BAM file on disk -> measureTE.parse_bampe -> TSV
+  single_cell               BASELINE config 4 (50 M records, 10 k cells) with an oracle sub-check
+  secondary                 BASELINE configs 2 (100 M SE, shuffled and coordinate-sorted) and 5 (3 M names)
+(`--legs headline` skips them.)
 """
 
 import argparse
@@ -21,6 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
@@ -38,10 +49,12 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the annotation (tests)')
     ap.add_argument('--bin-shift', type=int, default=0)
     ap.add_argument('--genes', type=int, default=40000, help='genes in the synthetic annotation (experiments)')
-    ap.add_argument('--cpu-sample', type=int, default=25_000_000, help='units timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=25_000_000, help='units timed on the C oracle (0 = skip the CPU baselines)')
     ap.add_argument('--traffic', default=None, help='HBM bytes per launch from rocprofv3 --pmc passes; default: profiles/traffic.json entry of this workload')
-    ap.add_argument('--host-stream', action='store_true', help='(default at N=1) also time the pinned-host -> HBM -> kernel path (PCIe-inclusive; reported beside, never as value)')
     ap.add_argument('--no-host-stream', action='store_true', help='skip the PCIe-inclusive measurement')
+    ap.add_argument('--legs', default='all', help="'all' (default at N=1), 'headline', or a comma list of: cpu,pcie,e2e,sc,secondary")
+    ap.add_argument('--e2e-records', type=int, default=16_000_000)
+    ap.add_argument('--sc-records', type=int, default=50_000_000)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -69,9 +82,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    paired = args.layout == 'pe'
-    n_units = args.records // 2 if paired else args.records
-    rec_per_unit = 2 if paired else 1
+    legs = set() if args.legs == 'headline' or world > 1 else \
+        ({'cpu', 'pcie', 'e2e', 'sc', 'secondary'} if args.legs == 'all' else set(args.legs.split(',')))
+    if args.no_host_stream:
+        legs.discard('pcie')
+    if not args.cpu_sample:
+        legs.discard('cpu')
 
     t0 = time.time()
     if args.genome == 'custom3m':
@@ -79,13 +95,9 @@ def main():
     else:
         ann = synth.make_annotation(args.genome, scale=args.scale, n_genes=args.genes)
     eng = Engine(local)
-    eng.upload_index(ann.flat, args.bin_shift)
-    info = eng.index_info()
-    units = synth.make_units(ann, n_units, seed=2003 + rank, paired=paired, order=args.order)
-    dev = [torch.from_numpy(u.view(np.int16) if u.dtype == np.uint16 else u).cuda() for u in units]
-    ptrs = [d.data_ptr() for d in dev]
-    torch.cuda.synchronize()
+    run = BulkRun(eng, ann, args.layout, args.order, args.records, seed=2003 + rank, bin_shift=args.bin_shift)
     t_setup = time.time() - t0
+    paired, n_units, rec_per_unit = run.paired, run.n_units, run.rec_per_unit
 
     d_counts, _ = eng.bulk_device_buffers()
 
@@ -96,7 +108,7 @@ def main():
     def job(steps):
         eng.bulk_begin(20)
         for _ in range(steps):
-            eng.bulk_submit_device(n_units, *ptrs)
+            eng.bulk_submit_device(n_units, *run.ptrs)
         if world > 1:
             eng.bulk_sync()
             dist.all_reduce(counts_t)  # RCCL sum over xGMI
@@ -121,6 +133,7 @@ def main():
         elapsed = float(t.item())
     kernel_ms, launches = eng.bulk_kernel_time()
     reduce_ms = eng.bulk_reduce_time()
+    launch_ms = eng.bulk_launch_times()
 
     # size-independent property at full size: K passes over one batch = K x one pass
     single, sstats = job(1)
@@ -131,10 +144,6 @@ def main():
     if rank == 0:
         total_records = n_units * rec_per_unit * args.steps * world
         value = total_records / elapsed / 1e6
-        # 15 B per unit + index (12 B per entry + 4 B per bin) + 8 B per name
-        alg_bytes = 15.0 * n_units + 12.0 * info['n_entries'] + 4.0 * info['n_bins'] + 8.0 * eng.n_names
-        avg_ms = kernel_ms / max(1, launches)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         out = {
             'metric': 'Mreads/s overlap-counted (bulk %s %s %s)' % (args.layout.upper(), args.genome, 'custom' if args.genome == 'custom3m' else 'genes_tes'),
             'value': round(value, 2), 'unit': 'Mreads/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -144,40 +153,102 @@ def main():
                                    '%d records/GPU/step, %s order, -q 20' % (args.layout.upper(), args.genome, len(ann.flat),
                                                                             ann.flat.n_names, n_units * rec_per_unit, args.order),
                        'records_per_gpu_per_step': n_units * rec_per_unit, 'units_per_launch': n_units,
-                       'index': info, 'parallelism': 'dp%d' % world,
+                       'index': run.info, 'parallelism': 'dp%d' % world,
                        'collective': ('%s all_reduce(sum) of u64 counts' % ('rccl' if backend == 'nccl' else backend)) if world > 1 else 'none',
                        'setup_s': round(t_setup, 1)},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic_for(args, n_units),
-                         'kernel': 'count_bulk_rec_kernel', 'avg_launch_ms': round(avg_ms, 4),
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'reduce_slabs_kernel_avg_ms': round(reduce_ms / max(1, launches), 4)},
+            'roofline': run.roofline(kernel_ms, launches, reduce_ms, launch_ms, traffic_for(args.traffic, args.genome, args.layout, args.order, n_units)),
             'assigned_frac': round(sstats['assigned'] / max(1, n_units), 4),
         }
-        tr = out['roofline']['traffic']
-        if tr:  # the rate at which the measured L2<->fabric bytes move: what actually bounds the shuffled case
-            out['roofline']['traffic_GBps'] = round(tr / (avg_ms * 1e-3) / 1e9, 1)
-        if not args.no_host_stream and world == 1:
-            out['pcie_inclusive'] = host_stream(eng, units, n_units, rec_per_unit)
-        if args.cpu_sample and world == 1:
-            out['cpu_baseline'] = cpu_baseline(ann, units, min(args.cpu_sample, n_units), rec_per_unit, eng)
+        t_legs = time.time()
+        if 'pcie' in legs:
+            out['pcie_inclusive'] = host_stream(eng, run.units, n_units, rec_per_unit)
+        if 'cpu' in legs:
+            out['cpu_baseline'] = cpu_baseline_python(ann, run.units, rec_per_unit, paired, eng)
+            out['cpu_baseline_c_1core'] = cpu_baseline_c(ann, run.units, min(args.cpu_sample, n_units), rec_per_unit, eng)
+            out['cpu_baseline_c_allcores'] = cpu_baseline_c_threads(ann, run.units, n_units, rec_per_unit, counts_one_pass=single)
+        run.release()
+        if 'e2e' in legs:
+            out['end_to_end_from_bam'] = leg(end_to_end, ann, eng, args.e2e_records)
+        if 'sc' in legs:
+            out['single_cell'] = leg(single_cell, ann, eng, args.sc_records)
+        if 'secondary' in legs:
+            out['secondary'] = leg(secondary, ann, eng, args)
+        if legs:
+            out['config']['legs_s'] = round(time.time() - t_legs, 1)
         print(json.dumps(out))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def traffic_for(args, n_units):
+class BulkRun:
+    """An index replica on the engine's GPU and one HBM-resident batch of synthetic units."""
+
+    def __init__(self, eng, ann, layout, order, records, seed, bin_shift=0):
+        import torch
+        from te_counter_amd import synth
+        self.eng, self.ann = eng, ann
+        self.paired = layout == 'pe'
+        self.rec_per_unit = 2 if self.paired else 1
+        self.n_units = records // 2 if self.paired else records
+        eng.upload_index(ann.flat, bin_shift)
+        self.info = eng.index_info()
+        self.units = synth.make_units(ann, self.n_units, seed=seed, paired=self.paired, order=order)
+        self.dev = [torch.from_numpy(u.view(np.int16) if u.dtype == np.uint16 else u).cuda() for u in self.units]
+        self.ptrs = [d.data_ptr() for d in self.dev]
+        torch.cuda.synchronize()
+
+    def algorithmic_bytes(self):
+        # SURVEY.md 8(d): 15 B per unit + index (12 B per entry + 4 B per bin) + 8 B per name
+        return 15.0 * self.n_units + 12.0 * self.info['n_entries'] + 4.0 * self.info['n_bins'] + 8.0 * self.eng.n_names
+
+    def roofline(self, kernel_ms, launches, reduce_ms, launch_ms, traffic):
+        alg = self.algorithmic_bytes()
+        avg_ms = kernel_ms / max(1, launches)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        r = {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'kernel': 'count_bulk_rec_kernel',
+             'avg_launch_ms': round(avg_ms, 4), 'algorithmic_bytes_per_launch': alg,
+             'reduce_slabs_kernel_avg_ms': round(reduce_ms / max(1, launches), 4)}
+        if len(launch_ms):  # per-launch durations from the event pool: the sample is short, show its spread
+            r['launch_ms_min_median_max'] = [round(float(np.min(launch_ms)), 4), round(float(np.median(launch_ms)), 4),
+                                             round(float(np.max(launch_ms)), 4)]
+        if traffic:  # the rate at which the measured L2<->fabric bytes move: what actually bounds the shuffled case
+            r['traffic_GBps'] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
+        return r
+
+    def count(self, steps):
+        self.eng.bulk_begin(20)
+        for _ in range(steps):
+            self.eng.bulk_submit_device(self.n_units, *self.ptrs)
+        return self.eng.bulk_finish()
+
+    def release(self):
+        self.dev = self.ptrs = None
+        import torch
+        torch.cuda.empty_cache()
+
+
+def leg(fn, *a):
+    """A side leg must not take the headline down with it -- except for parity failures, which are loud."""
+    try:
+        return fn(*a)
+    except SystemExit:
+        raise
+    except Exception as e:  # noqa: BLE001
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
+def traffic_for(explicit, genome, layout, order, n_units):
     """HBM bytes per launch of the count kernel from the committed rocprofv3 --pmc passes
     (profiles/traffic.json, written by tools/traffic.py); null if this workload was not profiled."""
-    if args.traffic:
-        return float(args.traffic)
+    if explicit:
+        return float(explicit)
     try:
         table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except (OSError, ValueError):
         return None
-    key = '%s/%s/%s/%d' % (args.genome, args.layout, args.order, n_units)
-    e = table.get(key)
+    e = table.get('%s/%s/%s/%d' % (genome, layout, order, n_units))
     return float(e['hbm_bytes_per_launch']) if e else None
 
 
@@ -201,7 +272,60 @@ def host_stream(eng, units, n_units, rec_per_unit, batch=1 << 24, reps=3):
             'note': 'pinned host batches streamed with hipMemcpyAsync, copy and compute streams overlapped'}
 
 
-def cpu_baseline(ann, units, n_sample, rec_per_unit, eng):
+def _host_cpus():
+    """CPUs this process may actually use: the cgroup quota if there is one (the GPU boxes show 256
+    logical CPUs and a quota of 16)."""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline_python(ann, units, rec_per_unit, paired, eng, n_sample=300_000):
+    """The reference's own loop as restated in plain Python (oracle/te_oracle.py: byte-identical to
+    te_count.py on the golden vectors) on ONE core -- all the reference can use -- over a bounded
+    sample: the first units of the batch that map to one chromosome, against that chromosome's part of
+    the annotation (the reference's 10 kb bucket lists are per chromosome, so the per-read work is that
+    of the genome-wide run; building Python buckets for all 5.7 M features would take minutes)."""
+    from oracle import te_oracle as orc
+    from te_counter_amd import synth
+    flat = ann.flat
+    chrom = int(np.bincount(units[0][units[0] >= 0][:5_000_000]).argmax()) if (units[0] >= 0).any() else 0
+    idx = np.nonzero(units[0] == chrom)[0][:n_sample]
+    sample = [u[idx] for u in units]
+    feats = synth.features_overlapping(flat, np.array([chrom]), np.array([0]), np.array([2 ** 31 - 2]))
+    name = ann.chrom_names[chrom]
+    recs = []
+    for p1, p2, fl, mq in zip(sample[1].tolist(), sample[2].tolist(), sample[3].tolist(), sample[4].tolist()):
+        if paired:
+            recs.append({'flag': fl, 'mapq': mq, 'qname': 'q', 'rname': name, 'pos': p1, 'end': p1 + 100})
+            recs.append({'flag': 0, 'mapq': mq, 'qname': 'q', 'rname': name, 'pos': p2, 'end': p2 + 100})
+        else:
+            recs.append({'flag': fl, 'mapq': mq, 'qname': 'q', 'rname': name, 'pos': p1, 'end': p2})
+    t = time.perf_counter()
+    buckets = orc.build_buckets(feats)
+    t_index = time.perf_counter() - t
+    t = time.perf_counter()
+    res, total, _ = orc.bulk_count(feats, recs, paired, buckets=buckets)
+    dt = time.perf_counter() - t
+    eng.bulk_begin(20)
+    eng.bulk_submit(*sample)
+    got, _ = eng.bulk_finish()
+    got = {n: int(c) for n, c in zip(flat.names, got) if c}
+    if got != {k: v for k, v in res.items() if v}:
+        raise SystemExit('PARITY FAILURE: GPU counts differ from the Python oracle on the bench sample')
+    return {'value': round(len(recs) / dt / 1e6, 4), 'unit': 'Mreads/s', 'cores': 1, 'kind': 'port',
+            'implementation': 'pure-Python restatement of te_count.py:76-152 / 201-263 (oracle/te_oracle.py)',
+            'sample': 'first %d units (%d records) of rank 0\'s batch on %s against that chromosome\'s %d features, %.1f s '
+                      '(+ %.1f s to build the Python buckets); GPU counts on the same sample are identical'
+                      % (len(idx), len(recs), name, len(feats), dt, t_index),
+            'cpu_model': _cpu_model(), 'host_cores': _host_cpus()}
+
+
+def cpu_baseline_c(ann, units, n_sample, rec_per_unit, eng):
     """The C oracle (oracle/te_oracle.c, the reference's loop restated) on one host core over a
     prefix of the same batch; also checks the GPU result on that prefix against it."""
     from oracle import c_oracle
@@ -217,9 +341,111 @@ def cpu_baseline(ann, units, n_sample, rec_per_unit, eng):
     if not ok:
         raise SystemExit('PARITY FAILURE: GPU counts differ from the oracle on the bench sample')
     return {'value': round(n_sample * rec_per_unit / dt / 1e6, 3), 'unit': 'Mreads/s', 'cores': 1, 'kind': 'port',
-            'sample': 'first %d units (%d records) of rank 0\'s batch, C restatement of the reference loop, '
-                      '%.1f s; GPU counts on the same sample are bit-identical' % (n_sample, n_sample * rec_per_unit, dt),
-            'cpu_model': _cpu_model(), 'host_cores': os.cpu_count()}
+            'implementation': 'C restatement of the reference loop (oracle/te_oracle.c)',
+            'sample': 'first %d units (%d records) of rank 0\'s batch, %.1f s; GPU counts on the same sample are bit-identical'
+                      % (n_sample, n_sample * rec_per_unit, dt),
+            'cpu_model': _cpu_model(), 'host_cores': _host_cpus()}
+
+
+def cpu_baseline_c_threads(ann, units, n_units, rec_per_unit, counts_one_pass):
+    """The C oracle on every core this process may use: threads over disjoint unit ranges (ctypes drops
+    the GIL), counts summed -- the strongest CPU baseline SURVEY.md 8(d) asks for.  The sum over the whole
+    batch must equal the GPU's one-pass counts."""
+    import concurrent.futures as cf
+    from oracle import c_oracle
+    ci = c_oracle.COracleIndex.from_flat(ann.flat)
+    threads = _host_cpus()
+    per = (n_units + threads - 1) // threads
+    ranges = [(a, min(n_units, a + per)) for a in range(0, n_units, per)]
+    t = time.perf_counter()
+    with cf.ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda r: ci.bulk_count(*[u[r[0]:r[1]] for u in units], 20)[0], ranges))
+    dt = time.perf_counter() - t
+    total = np.sum(parts, axis=0).astype(np.uint64)
+    if not np.array_equal(total, counts_one_pass):
+        raise SystemExit('PARITY FAILURE: the threaded C oracle over the whole batch differs from the GPU counts')
+    return {'value': round(n_units * rec_per_unit / dt / 1e6, 2), 'unit': 'Mreads/s', 'cores': threads, 'kind': 'port',
+            'implementation': 'C restatement of the reference loop, one thread per disjoint unit range',
+            'sample': 'the whole batch (%d units = %d records), %.1f s; summed counts equal the GPU\'s one-pass counts'
+                      % (n_units, n_units * rec_per_unit, dt),
+            'cpu_model': _cpu_model(), 'host_cores': threads}
+
+
+def end_to_end(ann, eng, records):
+    """What `te_count -i x.bam` does: a BAM file on disk -> on-GPU BGZF/BAM decode -> count kernel -> TSV
+    (tools/bench_e2e.py).  Two payloads: 'illumina' (ACGT + binned qualities, what sequencers write) and
+    'random' (incompressible sequence / quality bytes: the hard case for any inflater); the host decoder
+    (16-thread CPU inflate) on the same file beside it."""
+    import bench_e2e
+    out = {}
+    for payload, n in (('illumina', records), ('random', records // 2)):
+        r = bench_e2e.run(n, 'pe', payload, 'gpu', reps=2, ann=ann)
+        out[payload] = {'records': r['records'], 'bam_MB': r['bam_MB'],
+                        'first_run': r['run0_s'], 'warm_run': r['run1_s'], 'decode': r.get('decode_report'),
+                        'Mrecords_per_s_decode_and_count': r['Mrecords_per_s_decode_and_count'],
+                        'Mrecords_per_s_end_to_end_with_index_load': r['Mrecords_per_s_end_to_end'],
+                        'tsv_identical_to_oracle_formatting': r['tsv_ok']}
+        if payload == 'illumina':
+            h = bench_e2e.run(n, 'pe', payload, 'cpu', reps=1, ann=ann, reuse=r['bam_path'])
+            out['illumina_host_decoder'] = {'Mrecords_per_s_decode_and_count': h['Mrecords_per_s_decode_and_count'],
+                                            'threads': h['threads']}
+        bench_e2e.cleanup(r)
+    out['value'] = out['illumina']['Mrecords_per_s_decode_and_count']
+    out['unit'] = 'Mrecords/s (BAM file -> counts, one GPU, index resident)'
+    return out
+
+
+def single_cell(ann, eng, records):
+    """BASELINE config 4 through tec_sc_*: 10 k cells x 5 k reads, 737 280-barcode whitelist, 12-mer UMIs,
+    bundle threshold 1e7; a reduced-size run of the same generator is compared with the Python oracle."""
+    import bench_sc
+    from te_counter_amd import synth
+    res = bench_sc.oracle_check(eng, ann, 150_000, False)
+    if not res['identical']:
+        raise SystemExit('PARITY FAILURE in the reduced-size single-cell check')
+    eng.upload_index(ann.flat)
+    t0 = time.time()
+    arrays, wl, tables = synth.make_sc_arrays(ann, records, n_cells=10000, seed=2004)
+    gen_s = time.time() - t0
+    n = len(arrays['pos'])
+    bench_sc.run(eng, {k: v[:1 << 20] for k, v in arrays.items()}, wl, tables, 10000, False, 10_000_000)  # warm-up
+    out, st, t, _ = bench_sc.run(eng, arrays, wl, tables, 10000, False, 10_000_000)
+    gpu_ms = eng.sc_gpu_ms
+    alg = 32.0 * n  # SURVEY.md 8(d): 15 B + cb 8 + ub 8 + ub_len 1 per record
+    return {'metric': 'Mreads/s single-cell (--sc --se), host SoA batches -> COO counts', 'records': n,
+            'value': round(n / t['total'] / 1e6, 2), 'unit': 'Mreads/s',
+            'seconds': {k: round(v, 3) for k, v in t.items()}, 'gen_s': round(gen_s, 1), 'stats': st,
+            'cells_with_hits': int(len(out['cells'])), 'coo_nnz': int(len(out['coo_cell'])), 'oracle_check': res,
+            'roofline': {'bound': 'hbm', 'achieved': round(alg / (gpu_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(alg / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'kernel': 'all tec_sc_* kernels (filter, scatter, radix sorts, epochs, drop rule, query, RLE)',
+                         'gpu_stream_ms': round(gpu_ms, 2), 'algorithmic_bytes': alg}}
+
+
+def secondary(ann, eng, args):
+    """BASELINE configs 2 and 5 on the count kernel, each with its own roofline."""
+    from te_counter_amd import synth
+    out = {}
+    for key, a, layout, order, genome in (('config2_100M_SE_hg38_shuffled', ann, 'se', 'shuffled', 'hg38'),
+                                          ('config2_100M_SE_hg38_sorted', ann, 'se', 'sorted', 'hg38'),
+                                          ('config5_100M_SE_3M_names', None, 'se', 'shuffled', 'custom3m')):
+        if a is None:
+            a = synth.make_custom_annotation()
+        run = BulkRun(eng, a, layout, order, 100_000_000, seed=2002 if genome == 'hg38' else 2005)
+        run.count(2)
+        t = time.perf_counter()
+        counts, st = run.count(5)
+        dt = time.perf_counter() - t
+        kernel_ms, launches = eng.bulk_kernel_time()
+        single, _ = run.count(1)
+        if not np.array_equal(counts, single * 5):
+            raise SystemExit('PARITY FAILURE: linearity violated in ' + key)
+        out[key] = {'value': round(run.n_units * 5 / dt / 1e6, 1), 'unit': 'Mreads/s', 'ms_per_step': round(dt / 5 * 1e3, 4),
+                    'names': a.flat.n_names, 'assigned_frac': round(st['assigned'] / 5 / run.n_units, 4),
+                    'roofline': run.roofline(kernel_ms, launches, eng.bulk_reduce_time(), eng.bulk_launch_times(),
+                                             traffic_for(None, genome, layout, order, run.n_units))}
+        run.release()
+    return out
 
 
 def _cpu_model():

@@ -153,6 +153,10 @@ int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats);
  * launches since tec_bulk_begin; for bench.py's roofline figure. */
 int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* launches);
 
+/* The individual durations (ms) behind tec_bulk_kernel_time: *n = number of timed launches since
+ * tec_bulk_begin; the first min(capacity, *n) of them are written to ms (may be NULL). */
+int tec_bulk_launch_times(tec_ctx* ctx, float* ms, uint64_t capacity, uint64_t* n);
+
 /* Duration (ms) of the small kernels that fold the per-workgroup histogram rows into the count
  * vector after each count kernel, since tec_bulk_begin. */
 int tec_bulk_reduce_time(tec_ctx* ctx, double* total_ms);
@@ -180,6 +184,7 @@ typedef struct tec_sc_stats_t {
     uint64_t bundles;         /* spill epochs                                                  */
     uint64_t kept_lines;      /* "Preserved N" (te_count.py:545,572)                           */
     uint64_t assigned;        /* __read_assinged_to_feature (te_count.py:686)                  */
+    uint64_t gpu_us;          /* GPU stream time of submit + part 1 + parts 2/3, microseconds  */
 } tec_sc_stats_t;
 
 /* whitelist24: n_whitelist x 24 bytes, zero padded, strictly ascending bytewise == the order of
@@ -290,6 +295,7 @@ typedef struct tec_gbam_report {
     /* wall seconds of the decode loop by phase: waiting for the staging thread (pread into pinned memory),
      * H2D + inflate kernel, segment guess / walk / chain, row extraction (+ pairing, + count kernel) */
     double seconds_stage_wait, seconds_inflate, seconds_segments, seconds_rows;
+    double seconds_stage_alloc, seconds_stage_read; /* inside the staging thread: pinned allocation, pread */
 } tec_gbam_report;
 int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begin, uint64_t range_end, tec_gbam** out);
 void tec_gbam_close(tec_gbam* g);

@@ -77,12 +77,12 @@ def _bulk_hits(features, buckets, chrom, p1, p2):
     return hits
 
 
-def bulk_count(features, records, paired, quality_threshold=20, strand=False):
+def bulk_count(features, records, paired, quality_threshold=20, strand=False, buckets=None):
     """measureTE.parse_bamse (te_count.py:167-277) / parse_bampe (te_count.py:42-165).
     Returns (result dict ensg->int, total_reads, stats dict)."""
     if strand:
         raise NotImplementedError()  # te_count.py:58-59, 183-184
-    buckets = build_buckets(features)
+    buckets = buckets if buckets is not None else build_buckets(features)  # (pre-built: lets a caller time the loop alone)
     result = {n: 0 for n in feature_names(features)}
     stats = {'assigned': 0, 'lowq': 0, 'badchrom': 0, 'qcfail': 0}
     idx = 0

@@ -32,7 +32,7 @@ class Stats(C.Structure):
 
 class ScStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ('records', 'qcfail', 'lowq', 'invalid_barcode', 'skipped_chrom',
-                                          'survivors', 'keys', 'bundles', 'kept_lines', 'assigned')]
+                                          'survivors', 'keys', 'bundles', 'kept_lines', 'assigned', 'gpu_us')]
 
 
 _p = C.c_void_p
@@ -55,6 +55,7 @@ _SIGNATURES = {
     'tec_bulk_device_buffers': (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p)]),
     'tec_bulk_finish': (C.c_int, [_p, _p, C.POINTER(Stats)]),
     'tec_bulk_kernel_time': (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    'tec_bulk_launch_times': (C.c_int, [_p, _p, _u64, C.POINTER(_u64)]),
     'tec_bulk_reduce_time': (C.c_int, [_p, C.POINTER(C.c_double)]),
     'tec_sc_begin': (C.c_int, [_p, C.c_int, C.c_int, C.c_uint32, _p, _u64, C.c_uint32, _p, _p]),
     'tec_sc_submit': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),

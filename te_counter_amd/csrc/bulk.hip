@@ -1105,6 +1105,7 @@ int harvest_timers(tec_ctx* ctx) {
         float ms = 0.f;
         TEC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].start, ctx->ev_pool[i].stop));
         ctx->kernel_ms += ms;
+        if (ctx->launch_ms.size() < 65536) ctx->launch_ms.push_back(ms);
     }
     ctx->ev_used = 0;
     for (size_t i = 0; i < ctx->red_used; ++i) {
@@ -1364,6 +1365,7 @@ extern "C" int tec_bulk_begin(tec_ctx* ctx, int mapq_min) {
     ctx->reduce_ms = 0.0;
     ctx->kernel_launches = 0;
     ctx->timed_launches = 0;
+    ctx->launch_ms.clear();
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)ctx->idx.n_names + 2) * sizeof(unsigned long long), ctx->s_compute));
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), ctx->s_compute));
     ctx->bulk_open = true;
@@ -1503,6 +1505,16 @@ extern "C" int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* la
     if (rc) return rc;
     if (total_ms) *total_ms = ctx->kernel_ms;
     if (launches) *launches = ctx->timed_launches;  // the launches that carried timestamps (all of them by default)
+    return TEC_OK;
+}
+
+extern "C" int tec_bulk_launch_times(tec_ctx* ctx, float* ms, uint64_t capacity, uint64_t* n) {
+    if (!ctx || !n) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_launch_times: NULL argument");
+    int rc = tec_bulk_sync(ctx);
+    if (rc) return rc;
+    *n = ctx->launch_ms.size();
+    if (ms)
+        for (uint64_t i = 0; i < capacity && i < *n; ++i) ms[i] = ctx->launch_ms[i];
     return TEC_OK;
 }
 

@@ -68,12 +68,9 @@ struct DevMem {
     __device__ __forceinline__ void set_tab(uint32_t i, uint32_t v) { t[i * kInflThreads] = (uint16_t)v; }
     __device__ __forceinline__ uint32_t sym(uint32_t i) const { return s[i * 64u]; }
     __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
-    static __device__ __forceinline__ void store16(uint8_t* p, uint64_t lo, uint64_t hi) {
-        *reinterpret_cast<uint4*>(p) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-    }
 };
 
-__global__ __launch_bounds__(kInflThreads) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
+__global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
                                                                 uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed) {
     extern __shared__ uint16_t lds_tab[];
@@ -267,7 +264,19 @@ struct Staged {  // one chunk of compressed blocks in pinned host memory
 
 }  // namespace
 
-struct tec_gbam {
+// Device buffers and pinned staging of a reader.  They outlive the reader: tec_gbam_close parks them on the
+// context (allocating and freeing gigabytes of HBM and pinned memory costs more than decoding a small file),
+// the next reader on that context takes them over, tec_destroy frees them.
+struct GbamBuffers {
+    DBuf d_comp, d_desc, d_infl, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
+    DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
+    DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
+    DBuf d_flags;
+    uint64_t r_cap = 0, u_cap = 0;
+    Staged slots[2];
+};
+
+struct tec_gbam : GbamBuffers {
     tec_ctx* ctx = nullptr;
     int fd = -1;
     uint64_t file_size = 0;
@@ -279,16 +288,10 @@ struct tec_gbam {
     uint64_t first_data_off = 0;     // file offset of the first BGZF block this reader stages
     uint64_t hdr_block_off = 0;      // range 0: block that holds the first record ...
     uint32_t hdr_inblock = 0;        // ... and its offset inside that block's inflated bytes
-    size_t chunk_bytes = 512u << 20;
+    // one chunk = one launch of the inflate kernel: 128 lanes x 256 CUs = 32768 blocks fill the chip exactly once
+    size_t chunk_bytes = 2047u << 20;
     uint32_t chunk_blocks = 32768;
-    // device
-    DBuf d_comp, d_desc, d_infl, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
-    DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
-    DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
-    uint64_t r_cap = 0, u_cap = 0;
-    uint32_t n_tid = 0;
-    // pinned staging ring
-    Staged slots[2];
+    int read_threads = 8;
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
     bool start_known = false;
@@ -296,11 +299,12 @@ struct tec_gbam {
     uint64_t tok_first[2] = {0, 0}, tok_end[2] = {0, 0};
     uint64_t blocks = 0, blocks_host = 0, comp_bytes = 0, infl_bytes = 0, repairs = 0;
     double t_stage_wait = 0, t_inflate = 0, t_segments = 0, t_rows = 0;  // seconds of the decode loop, by phase
+    double t_stage_alloc = 0, t_stage_read = 0;                          // staging thread: pinned allocation, pread
     // deferred PE pairing
     bool deferred = false;
     uint64_t n_resident = 0;  // records kept in r_* (deferred mode), starting at row 1
     bool skip_header = false;  // the next chunk is the start of the file: records begin behind the BAM header
-    DBuf d_flags;
+    uint32_t n_tid = 0;
 };
 
 namespace {
@@ -336,6 +340,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         return;
     }
     const size_t want = (size_t)std::min<uint64_t>(g->chunk_bytes + 65536 + 64, g->file_size - off);
+    double t0 = now_s();
     if (want + 32 > st->pinned_cap) {
         if (st->pinned) (void)hipHostFree(st->pinned);
         st->pinned = nullptr;
@@ -348,9 +353,11 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         st->pinned = static_cast<uint8_t*>(p);
         st->pinned_cap = want + 32;
     }
+    g->t_stage_alloc += now_s() - t0;
+    t0 = now_s();
     // parallel pread: page cache -> pinned memory
     {
-        const int nt = want > (32u << 20) ? 8 : 1;
+        const int nt = want > (32u << 20) ? g->read_threads : 1;
         std::vector<std::thread> th;
         std::vector<int> ok(nt, 1);
         const size_t per = (want + nt - 1) / nt;
@@ -374,6 +381,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
                 return;
             }
     }
+    g->t_stage_read += now_s() - t0;
     memset(st->pinned + want, 0, 32);
     size_t o = 0;
     uint64_t infl = 0;
@@ -706,6 +714,12 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     if (rc != TEC_OK) return tec_fail(ctx, rc, "%s", tec_bam_last_error(nullptr));
     std::unique_ptr<tec_gbam> g(new tec_gbam());
     g->ctx = ctx;
+    if (ctx->gbam_cache) {  // buffers parked by the previous reader on this context
+        GbamBuffers* c = static_cast<GbamBuffers*>(ctx->gbam_cache);
+        static_cast<GbamBuffers&>(*g) = *c;
+        delete c;
+        ctx->gbam_cache = nullptr;
+    }
     const int n_ref = tec_bam_n_refs(hb);
     for (int i = 0; i < n_ref; ++i) g->ref_names.emplace_back(tec_bam_ref_name(hb, i));
     g->ref_lens.resize((size_t)n_ref);
@@ -726,6 +740,10 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     if (const char* e = getenv("TEC_GBAM_CHUNK_MB")) {
         const long mb = atol(e);
         if (mb >= 1 && mb <= 3072) g->chunk_bytes = (size_t)mb << 20;
+    }
+    if (const char* e = getenv("TEC_GBAM_READ_THREADS")) {
+        const long nt = atol(e);
+        if (nt >= 1 && nt <= 64) g->read_threads = (int)nt;
     }
     if (const char* e = getenv("TEC_GBAM_CHUNK_BLOCKS")) {
         const long nb = atol(e);
@@ -777,18 +795,34 @@ extern "C" const char* tec_gbam_ref_name(const tec_gbam* g, int i) {
 }
 extern "C" uint64_t tec_gbam_file_size(const tec_gbam* g) { return g ? g->file_size : 0; }
 
+static void free_buffers(GbamBuffers* g) {
+    for (DBuf* b : {&g->d_comp, &g->d_desc, &g->d_infl, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
+                    &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
+                    &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
+        b->release();
+    for (auto& s : g->slots)
+        if (s.pinned) (void)hipHostFree(s.pinned);
+}
+
+void tec_gbam_cache_release(tec_ctx* ctx) {
+    if (!ctx || !ctx->gbam_cache) return;
+    GbamBuffers* c = static_cast<GbamBuffers*>(ctx->gbam_cache);
+    free_buffers(c);
+    delete c;
+    ctx->gbam_cache = nullptr;
+}
+
 extern "C" void tec_gbam_close(tec_gbam* g) {
     if (!g) return;
     if (g->ctx) {
         (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->s_compute);
     }
-    for (DBuf* b : {&g->d_comp, &g->d_desc, &g->d_infl, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land,
-                    &g->d_offs, &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
-                    &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
-        b->release();
-    for (auto& s : g->slots)
-        if (s.pinned) (void)hipHostFree(s.pinned);
+    if (g->ctx && !g->ctx->gbam_cache) {
+        g->ctx->gbam_cache = new GbamBuffers(static_cast<GbamBuffers&>(*g));  // parked for the next reader
+    } else {
+        free_buffers(g);
+    }
     if (g->fd >= 0) close(g->fd);
     delete g;
 }
@@ -1018,6 +1052,8 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
         rep->seconds_inflate = g->t_inflate;
         rep->seconds_segments = g->t_segments;
         rep->seconds_rows = g->t_rows;
+        rep->seconds_stage_alloc = g->t_stage_alloc;
+        rep->seconds_stage_read = g->t_stage_read;
         rep->units_counted = rs.units_done;
         rep->odd_record_left = rs.have_odd ? 1 : 0;
         if (a.mode == kModePE && a.deferred && g->n_resident) {

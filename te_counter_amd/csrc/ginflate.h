@@ -13,10 +13,13 @@
 //   * codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit,
 //     from per-length counts packed in registers; only their symbols live in global scratch;
 //   * base values and extra-bit counts of length / distance symbols are computed arithmetically;
-//   * output goes through a 16-byte register accumulator and leaves as aligned 16-byte stores; the
-//     last 32-47 bytes stay addressable in registers, so matches at distance <= 32 (runs, short
-//     periods) never read memory, and farther matches read memory that is certainly written;
+//   * literals are stored as they are decoded; matches are copied eight bytes per round trip (a run of
+//     one byte needs no loads at all);
 //   * input arrives as 8-byte loads issued one step ahead of their use.
+// Two other formulations were measured on the MI355X and lost to this one: routing all
+// output through a 16-byte register accumulator, and a flat one-byte-per-step state machine with all
+// memory traffic at common sync points -- both removed the memory waits and both paid for it with
+// three to four times the instructions per symbol.
 //
 // Replaces, on the device, the BGZF inflation that the reference gets from pysam / htslib
 // (te_count/te_count.py:65,190,351); follows RFC 1951 only.
@@ -51,7 +54,6 @@ enum : int { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kB
 // memory; the host instantiation uses plain arrays.
 //   uint32_t tab(uint32_t i) / void set_tab(uint32_t i, uint32_t v)     i < kEntriesPerLane
 //   uint32_t sym(uint32_t i) / void set_sym(uint32_t i, uint32_t v)     i < kLongSymsPerLane
-//   void store16(uint8_t* aligned16, uint64_t lo, uint64_t hi)
 struct HostMem {
     uint16_t t[kEntriesPerLane];
     uint16_t s[kLongSymsPerLane];
@@ -59,10 +61,6 @@ struct HostMem {
     void set_tab(uint32_t i, uint32_t v) { t[i] = (uint16_t)v; }
     uint32_t sym(uint32_t i) const { return s[i]; }
     void set_sym(uint32_t i, uint32_t v) { s[i] = (uint16_t)v; }
-    static void store16(uint8_t* p, uint64_t lo, uint64_t hi) {
-        memcpy(p, &lo, 8);
-        memcpy(p + 8, &hi, 8);
-    }
 };
 
 // Code lengths as nibbles in table entries [kLenArea, kLenArea + 80): four per 16-bit entry.
@@ -180,58 +178,6 @@ struct BitReader {
     TEC_HD bool far_overrun() const { return taken > (uint32_t)(in_end - in) + 16u; }
 };
 
-// Output: bytes collect in a 16-byte group that maps onto a 16-byte ALIGNED window of the output
-// address space; a completed group leaves as one aligned store.  The two groups before it stay in
-// registers: together with the current one they answer every read at distance <= 32.
-template <class Mem>
-struct OutAcc {
-    uint8_t* out;
-    uint32_t out_len, op, mis;  // mis = address of out modulo 16
-    uint64_t c_lo, c_hi, p_lo, p_hi, q_lo, q_hi;  // current, previous, the one before
-    TEC_HD void start(uint8_t* o, uint32_t n) {
-        out = o;
-        out_len = n;
-        op = 0;
-        mis = (uint32_t)((uintptr_t)o & 15u);
-        c_lo = c_hi = p_lo = p_hi = q_lo = q_hi = 0;
-    }
-    static TEC_HD uint8_t byte_of(uint64_t lo, uint64_t hi, uint32_t j) { return (uint8_t)((j < 8u ? lo : hi) >> (8u * (j & 7u))); }
-    TEC_HD void put(uint32_t b) {  // caller checked op < out_len
-        const uint32_t k = (op + mis) & 15u;
-        const uint64_t v = (uint64_t)(b & 255u) << (8u * (k & 7u));
-        c_lo |= k < 8u ? v : 0ull;
-        c_hi |= k < 8u ? 0ull : v;
-        ++op;
-        if (k == 15u) {
-            if (op >= 16u) {
-                Mem::store16(out + (op - 16u), c_lo, c_hi);
-            } else {  // the block's first group starts before `out`: only its own bytes may be written
-                for (uint32_t j = 16u - op; j < 16u; ++j) out[j - (16u - op)] = byte_of(c_lo, c_hi, j);
-            }
-            q_lo = p_lo;
-            q_hi = p_hi;
-            p_lo = c_lo;
-            p_hi = c_hi;
-            c_lo = c_hi = 0;
-        }
-    }
-    // the byte written d positions ago, 1 <= d <= 32 (and d <= op)
-    TEC_HD uint32_t back(uint32_t d) const {
-        const uint32_t k = (op + mis) & 15u;       // bytes in the current group
-        const uint32_t j = (k + 48u - d) & 15u;    // position inside its group
-        const uint32_t g = d <= k ? 0u : (d <= k + 16u ? 1u : 2u);
-        const uint64_t lo = g == 0u ? c_lo : (g == 1u ? p_lo : q_lo);
-        const uint64_t hi = g == 0u ? c_hi : (g == 1u ? p_hi : q_hi);
-        return byte_of(lo, hi, j);
-    }
-    // the unfinished last group
-    TEC_HD void finish() {
-        const uint32_t k = (op + mis) & 15u;
-        const uint32_t own = k < op ? k : op;  // bytes of the group that belong to this block
-        for (uint32_t j = 0; j < own; ++j) out[op - own + j] = byte_of(c_lo, c_hi, k - own + j);
-    }
-};
-
 TEC_HD uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32u - len); }
 
 // Canonical Huffman tables of one code (RFC 1951 3.2.2).  lens(i), i < n: code lengths.  Entries
@@ -314,8 +260,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
     br.in = in;
     br.in_end = in + in_len;
     br.start(in);
-    OutAcc<Mem> oa;
-    oa.start(out, out_len);
+    uint32_t op = 0;
     bool last = false;
     while (!last) {
         br.refill();
@@ -331,15 +276,17 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if ((len ^ nlen) != 0xFFFFu) return kBadStored;
             const uint32_t pos = br.byte_pos();  // whole bytes still in the bit buffer belong to the payload
             if (pos > in_len || in_len - pos < len) return kInputOverrun;
-            if (out_len - oa.op < len) return kOutputOverrun;
+            if (out_len - op < len) return kOutputOverrun;
             const uint8_t* src = in + pos;
+            uint8_t* q = out + op;
             uint32_t k = 0;
             for (; k + 8u <= len; k += 8u) {
                 uint64_t v;
                 memcpy(&v, src + k, 8);
-                for (uint32_t j = 0; j < 8u; ++j) oa.put((uint32_t)(v >> (8u * j)));
+                memcpy(q + k, &v, 8);
             }
-            for (; k < len; ++k) oa.put(src[k]);
+            for (; k < len; ++k) q[k] = src[k];
+            op += len;
             br.start(src + len);
             continue;
         }
@@ -427,8 +374,8 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 if (s == 0xFFFFu) return kBadSymbol;
             }
             if (s < 256u) {
-                if (oa.op >= out_len) return kOutputOverrun;
-                oa.put(s);
+                if (op >= out_len) return kOutputOverrun;
+                out[op++] = (uint8_t)s;
                 continue;
             }
             if (s == 256u) break;
@@ -454,35 +401,37 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             uint32_t dist = d < 4u ? 1u + d : 1u + ((2u + (d & 1u)) << dx);
             br.refill();
             dist += br.get(dx);
-            if (dist > oa.op) return kBadDistance;
-            if (out_len - oa.op < length) return kOutputOverrun;
+            if (dist > op) return kBadDistance;
+            if (out_len - op < length) return kOutputOverrun;
             if (br.far_overrun()) return kInputOverrun;
-            if (dist == 1u) {  // a run of one byte (quality strings)
-                const uint32_t v = oa.back(1);
-                for (uint32_t k = 0; k < length; ++k) oa.put(v);
-            } else if (dist <= 32u) {  // the source is still in registers
-                for (uint32_t k = 0; k < length; ++k) oa.put(oa.back(dist));
-            } else {  // the source was stored at least one whole group ago
+            uint8_t* q = out + op;
+            const uint8_t* p = q - dist;
+            op += length;
+            if (dist == 1u) {  // a run of one byte (quality strings): no loads beyond the one byte
+                const uint64_t v = 0x0101010101010101ull * (uint64_t)*p;
+                uint32_t k = 0;
+                for (; k + 8u <= length; k += 8u) memcpy(q + k, &v, 8);
+                for (; k < length; ++k) q[k] = (uint8_t)v;
+            } else if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
                 uint32_t k = 0;
                 for (; k + 8u <= length; k += 8u) {
                     uint64_t v;
-                    memcpy(&v, oa.out + (oa.op - dist), 8);
-                    for (uint32_t j = 0; j < 8u; ++j) oa.put((uint32_t)(v >> (8u * j)));
+                    memcpy(&v, p + k, 8);
+                    memcpy(q + k, &v, 8);
                 }
-                if (k < length) {
+                if (k < length) {  // the tail: read it whole, then write it
                     uint64_t v = 0;
-                    const uint8_t* p = oa.out + (oa.op - dist);
-                    for (uint32_t j = 0; j < length - k; ++j) v |= (uint64_t)p[j] << (8u * j);
-                    for (uint32_t j = 0; k < length; ++k, ++j) oa.put((uint32_t)(v >> (8u * j)));
+                    for (uint32_t j = 0; k + j < length; ++j) v |= (uint64_t)p[k + j] << (8u * j);
+                    for (uint32_t j = 0; k + j < length; ++j) q[k + j] = (uint8_t)(v >> (8u * j));
                 }
+            } else {
+                for (uint32_t k = 0; k < length; ++k) q[k] = p[k];
             }
         }
         if (br.far_overrun()) return kInputOverrun;
     }
     if (br.overrun()) return kInputOverrun;
-    if (oa.op != out_len) return kShortOutput;
-    oa.finish();
-    return kOk;
+    return op == out_len ? kOk : kShortOutput;
 }
 
 }  // namespace tec_ginf

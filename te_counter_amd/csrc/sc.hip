@@ -100,6 +100,10 @@ struct tec_sc_state {
     std::vector<uint64_t> out_hits, coo_count;
     uint64_t kept_lines = 0, n_queries = 0, n_assigned = 0;
     unsigned long long h_stat[ST_N] = {0};
+    // GPU stream time of the phases (events around each entry point's work; includes the short host gaps
+    // between its kernels, so it is an upper bound of the summed kernel time)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double gpu_ms = 0.0;
 };
 
 namespace {
@@ -575,6 +579,8 @@ void sc_free(tec_sc_state* s) {
     s->s_u0.release(); s->s_u1.release(); s->s_u2.release(); s->k32a.release(); s->k32b.release();
     s->s_klass.release(); s->s_left.release(); s->s_rite.release(); s->ghead.release(); s->ihead.release();
     s->counted.release();
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
 }
 
@@ -645,12 +651,33 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
 }
 
 namespace {
+struct PhaseTimer {  // accumulates the stream time between construction and stop()
+    tec_ctx* ctx;
+    tec_sc_state* s;
+    bool on = false;
+    PhaseTimer(tec_ctx* c, tec_sc_state* st) : ctx(c), s(st) {
+        if (!s->ev0 && hipEventCreate(&s->ev0) != hipSuccess) return;
+        if (!s->ev1 && hipEventCreate(&s->ev1) != hipSuccess) return;
+        on = hipEventRecord(s->ev0, ctx->s_compute) == hipSuccess;
+    }
+    void stop() {
+        if (!on) return;
+        on = false;
+        float ms = 0.f;
+        if (hipEventRecord(s->ev1, ctx->s_compute) == hipSuccess && hipEventSynchronize(s->ev1) == hipSuccess &&
+            hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess)
+            s->gpu_ms += ms;
+    }
+    ~PhaseTimer() { stop(); }
+};
+
 // Filters + order-preserving compaction of one batch that is resident in HBM (te_count.py:394-433).
 // Returns after the batch has been consumed: the input buffers are free again.
 int sc_ingest(tec_ctx* ctx, tec_sc_state* s, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
               const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb, const uint8_t* d_ub, const uint8_t* d_tf) {
     hipStream_t st = ctx->s_compute;
     SC_HIP(s->b_live.reserve(n));
+    PhaseTimer timer(ctx, s);
     SC_HIP(s->b_scan.reserve(n));
     SC_HIP(s->b_bcid.reserve(n));
     hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, d_cls, d_flag, d_mapq, d_cb, d_tf,
@@ -740,6 +767,7 @@ extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
     hipStream_t st = ctx->s_compute;
     SC_HIP(hipStreamSynchronize(st));
     SC_HIP(hipMemcpy(s->h_stat, s->stat.p, sizeof s->h_stat, hipMemcpyDeviceToHost));
+    PhaseTimer timer(ctx, s);
     s->part1_done = true;
     s->cells_seen.clear();
     s->cells_count.clear();
@@ -898,6 +926,7 @@ extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* 
     if (n_coo) *n_coo = 0;
     const uint64_t N = s->n_live;
     if (N == 0 || n_selected == 0) return TEC_OK;
+    PhaseTimer timer(ctx, s);
     for (uint32_t i = 0; i < n_selected; ++i)
         if (selected_bcid[i] >= s->n_wl || (i && selected_bcid[i] <= selected_bcid[i - 1]))
             return tec_fail(ctx, TEC_EINVAL, "tec_sc_part23: selected barcodes must be ascending whitelist ids");
@@ -1092,6 +1121,7 @@ extern "C" int tec_sc_stats(tec_ctx* ctx, tec_sc_stats_t* out) {
     out->bundles = s->n_live ? s->n_epochs : 0;
     out->kept_lines = s->kept_lines;
     out->assigned = s->n_assigned;
+    out->gpu_us = (uint64_t)(s->gpu_ms * 1000.0);
     return TEC_OK;
 }
 

@@ -66,6 +66,7 @@ struct tec_ctx {
 
     // single cell
     tec_sc_state* sc = nullptr;
+    void* gbam_cache = nullptr;  // device / pinned buffers parked by the last on-GPU BAM reader (gbam.hip)
 
     // bulk state
     bool bulk_open = false;
@@ -78,6 +79,7 @@ struct tec_ctx {
     std::vector<tec_event_pair> ev_pool;
     size_t ev_used = 0;
     double kernel_ms = 0.0, reduce_ms = 0.0;
+    std::vector<float> launch_ms;  // duration of every timed count-kernel launch since tec_bulk_begin
     uint32_t* d_slabs = nullptr;  // [workgroups x histogram words] per-workgroup histogram rows of a launch
     size_t slab_cap = 0;
     int time_every = 1;
@@ -119,6 +121,8 @@ int tec_bulk_init(tec_ctx* ctx);
 int tec_bulk_release(tec_ctx* ctx);
 // sc.hip
 void tec_sc_release(tec_ctx* ctx);
+// gbam.hip
+void tec_gbam_cache_release(tec_ctx* ctx);
 // bamio.hip: BGZF helpers shared with gbam.hip
 size_t tec_bgzf_find_block(const uint8_t* m, size_t len, size_t from);
 bool tec_bgzf_parse(const uint8_t* m, size_t len, size_t o, size_t* bsize, size_t* body_off, size_t* body_len, uint32_t* isize);

@@ -109,6 +109,15 @@ class Engine:
         self._check(self._lib.tec_bulk_kernel_time(self._ctx, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
 
+    def bulk_launch_times(self):
+        """Per-launch durations (ms) of the count kernel since bulk_begin (HIP events on its stream)."""
+        n = C.c_uint64()
+        self._check(self._lib.tec_bulk_launch_times(self._ctx, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            self._check(self._lib.tec_bulk_launch_times(self._ctx, _ptr(out), n.value, C.byref(n)))
+        return out
+
     def bulk_reduce_time(self):
         ms = C.c_double()
         self._check(self._lib.tec_bulk_reduce_time(self._ctx, C.byref(ms)))
@@ -166,7 +175,8 @@ class Engine:
     def sc_stats(self):
         st = _lib.ScStats()
         self._check(self._lib.tec_sc_stats(self._ctx, C.byref(st)))
-        return {k: int(getattr(st, k)) for k, _ in _lib.ScStats._fields_}
+        self.sc_gpu_ms = int(st.gpu_us) / 1000.0  # GPU stream time of the run's phases (not part of the log counters)
+        return {k: int(getattr(st, k)) for k, _ in _lib.ScStats._fields_ if k != 'gpu_us'}
 
     def sc_end(self):
         self._check(self._lib.tec_sc_end(self._ctx))

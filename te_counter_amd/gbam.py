@@ -31,7 +31,8 @@ class GbamReport(C.Structure):
                 ('units_counted', C.c_uint64), ('odd_record_left', C.c_int), ('first_rec', GbamRec), ('last_rec', GbamRec),
                 ('blocks', C.c_uint64), ('blocks_redone_on_host', C.c_uint64), ('compressed_bytes', C.c_uint64),
                 ('inflated_bytes', C.c_uint64), ('segment_repairs', C.c_uint64), ('seconds_stage_wait', C.c_double),
-                ('seconds_inflate', C.c_double), ('seconds_segments', C.c_double), ('seconds_rows', C.c_double)]
+                ('seconds_inflate', C.c_double), ('seconds_segments', C.c_double), ('seconds_rows', C.c_double),
+                ('seconds_stage_alloc', C.c_double), ('seconds_stage_read', C.c_double)]
 
     def as_dict(self):
         return {'n_records': int(self.n_records), 'has_records': bool(self.has_records),
@@ -44,7 +45,8 @@ class GbamReport(C.Structure):
                 'compressed_bytes': int(self.compressed_bytes), 'inflated_bytes': int(self.inflated_bytes),
                 'segment_repairs': int(self.segment_repairs),
                 'seconds': {'stage_wait': round(self.seconds_stage_wait, 4), 'inflate': round(self.seconds_inflate, 4),
-                            'segments': round(self.seconds_segments, 4), 'rows': round(self.seconds_rows, 4)}}
+                            'segments': round(self.seconds_segments, 4), 'rows': round(self.seconds_rows, 4),
+                            'stage_alloc': round(self.seconds_stage_alloc, 4), 'stage_read': round(self.seconds_stage_read, 4)}}
 
 
 def is_bgzf(path):

@@ -112,10 +112,6 @@ def test_not_a_bam(tmp_path):
 def test_chunked_reader_threads_and_batches(tmp_path):
     """A file of several 512-block chunks: every thread count and batch size must give the same rows
     (records straddle BGZF blocks, thread shares and chunks; batches end in the middle of chunks)."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
-    import bench_e2e
     n = 330_001
     rng = np.random.default_rng(8)
     tid = rng.integers(0, 3, n).astype(np.int32)
@@ -123,7 +119,7 @@ def test_chunked_reader_threads_and_batches(tmp_path):
     flag = rng.integers(0, 4096, n).astype(np.uint16)
     mapq = rng.integers(0, 256, n).astype(np.uint8)
     path = str(tmp_path / 'big.bam')
-    bench_e2e.write_bam_fast(path, ['chr1', 'chr2', 'chrUn'], tid, pos, flag, mapq, pair_names=True)
+    bam.write_bam_arrays(path, ['chr1', 'chr2', 'chrUn'], tid, pos, flag, mapq, pair_names=True)
     assert os.path.getsize(path) > 40_000_000  # > 512 blocks of 64 KiB
     ref = None
     for threads, batch in [(1, 1 << 22), (3, 77_777), (8, 1000), (8, 1 << 22), (5, 130_000)]:

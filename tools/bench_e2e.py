@@ -17,24 +17,37 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(records, layout='pe', payload='random', decoder='gpu', scale=1.0, reps=2, keep_dir=None):
+def cleanup(result):
+    import shutil
+    shutil.rmtree(result.get('dir', ''), ignore_errors=True)
+
+
+def run(records, layout='pe', payload='random', decoder='gpu', scale=1.0, reps=2, ann=None, reuse=None):
+    """reuse: path of a BAM written by an earlier call with the same arguments (it is not rewritten).
+    The temporary directory stays until cleanup(result)."""
     from te_counter_amd import bam, synth
     from te_counter_amd.measure import measureTE
     paired = layout == 'pe'
-    ann = synth.make_annotation('hg38', scale=scale)
+    ann = ann or synth.make_annotation('hg38', scale=scale)
     n_units = records // 2 if paired else records
     units = synth.make_units(ann, n_units, seed=4242, paired=paired)
     refs = ann.chrom_names + ['chrUn_1']
-    tid, pos, fl, mq = bam.units_to_records(units, len(refs) - 1, paired)
     out = {'layout': layout, 'payload': payload, 'decoder': decoder}
+    prev = os.environ.get('TEC_DECODER')
     os.environ['TEC_DECODER'] = decoder
-    with tempfile.TemporaryDirectory(dir=keep_dir) as td:
-        bam_path, idx_path, tsv = os.path.join(td, 'in.bam'), os.path.join(td, 'ann.tecidx'), os.path.join(td, 'out.tsv')
-        t = time.time()
-        bam.write_bam_arrays(bam_path, refs, tid, pos, fl, mq, end=None if paired else units[2], pair_names=paired, payload=payload)
-        out['write_bam_s'] = round(time.time() - t, 2)
+    td = os.path.dirname(reuse) if reuse else tempfile.mkdtemp(dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    out['dir'] = td
+    try:
+        bam_path, idx_path, tsv = os.path.join(td, 'in.bam'), os.path.join(td, 'ann.tecidx'), os.path.join(td, 'out.%s.tsv' % decoder)
+        out['bam_path'] = bam_path
+        if not reuse:
+            tid, pos, fl, mq = bam.units_to_records(units, len(refs) - 1, paired)
+            t = time.time()
+            bam.write_bam_arrays(bam_path, refs, tid, pos, fl, mq, end=None if paired else units[2], pair_names=paired, payload=payload)
+            out['write_bam_s'] = round(time.time() - t, 2)
+            ann.flat.save(idx_path)
         out['bam_MB'] = round(os.path.getsize(bam_path) / 1e6, 1)
-        ann.flat.save(idx_path)
+        n_rec = n_units * (2 if paired else 1)
         for rep in range(reps):  # the first run pays library loading and buffer allocation
             t0 = time.time()
             mte = measureTE('bench_e2e', 20)
@@ -53,10 +66,24 @@ def run(records, layout='pe', payload='random', decoder='gpu', scale=1.0, reps=2
                                                           'segment_repairs', 'seconds')}
             mte._engine.close()
         out['tsv_lines'] = sum(1 for _ in open(tsv))
+        # the TSV against the C oracle's counts in the reference writer's formatting (te_count.py:279-296)
+        from oracle import c_oracle
+        from oracle import te_oracle as orc
+        want, _ = c_oracle.COracleIndex.from_flat(ann.flat).bulk_count(*[u[:2_000_000] for u in units], 20) if n_units <= 2_000_000 else (None, None)
+        if want is not None:
+            out['tsv_ok'] = open(tsv).read() == orc.format_bulk_tsv({n: int(c) for n, c in zip(ann.flat.names, want)}, n_units + 1)
+        else:  # large runs: the count column must sum to what the engine reported as counted
+            out['tsv_ok'] = sum(int(line.split('\t')[1]) for line in open(tsv)) == int(sum(result.values()))
+    finally:
+        if prev is None:
+            os.environ.pop('TEC_DECODER', None)
+        else:
+            os.environ['TEC_DECODER'] = prev
     last = out['run%d_s' % (reps - 1)]
-    out['records'] = int(len(tid))
-    out['Mrecords_per_s_decode_and_count'] = round(len(tid) / last['decode_and_count'] / 1e6, 2)
-    out['Mrecords_per_s_end_to_end'] = round(len(tid) / last['total'] / 1e6, 2)
+    out['records'] = int(n_rec)
+    out['Mrecords_per_s_decode_and_count'] = round(n_rec / last['decode_and_count'] / 1e6, 2)
+    out['Mrecords_per_s_end_to_end'] = round(n_rec / last['total'] / 1e6, 2)
+    out['threads'] = int(os.environ.get('TEC_BAM_THREADS', 16))
     out['host_cores'] = os.cpu_count()
     return out
 
@@ -70,7 +97,9 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0)
     ap.add_argument('--reps', type=int, default=3)
     args = ap.parse_args()
-    print(json.dumps(run(args.records, args.layout, args.payload, args.decoder, args.scale, args.reps)))
+    r = run(args.records, args.layout, args.payload, args.decoder, args.scale, args.reps)
+    cleanup(r)
+    print(json.dumps(r))
 
 
 if __name__ == '__main__':

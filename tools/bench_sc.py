@@ -47,6 +47,30 @@ def run(eng, arrays, wl, tables, maxcells, stranded, bundle_keys, batch=1 << 22)
     return out, st, t, (ids, counts)
 
 
+def oracle_check(eng, ann, n_records, strand):
+    """A reduced-size run of the config-4 generator (same annotation family at 1 % scale, several spill
+    epochs) on the GPU against the Python oracle: result dict and per-cell totals must be identical."""
+    from oracle import te_oracle as orc
+    from te_counter_amd import synth
+    small = synth.make_annotation(ann.genome if ann.genome in synth.GENOMES else 'hg38', scale=0.01)
+    eng.upload_index(small.flat)
+    arrays, wl, tables = synth.make_sc_arrays(small, n_records, n_cells=40, n_whitelist=5000, seed=11)
+    thr = max(1000, n_records // 8)
+    out, st, _, _ = run(eng, arrays, wl, tables, 25, strand, thr)
+    wl_str = [bytes(r).rstrip(b'\0').decode() for r in wl]
+    feats = [{'chr': small.flat.chrom_keys[c], 'left': int(l), 'right': int(r), 'strand': '+-'[(m >> 29) & 1],
+              'name': 'x', 'type': 'TE' if ((m >> 26) & 7) == 2 else 'protein_coding', 'ensg': small.flat.names[m & ((1 << 26) - 1)]}
+             for c, l, r, m in zip(small.flat.chrom_id.tolist(), small.flat.left.tolist(), small.flat.right.tolist(), small.flat.meta.tolist())]
+    recs = synth.sc_arrays_to_records(arrays, tables[0])
+    want, wbc, _ = orc.sc_count(feats, recs, wl_str, 25, strand=strand, bundle_threshold=thr)
+    got = {}
+    for c, nm, v in zip(out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()):
+        got.setdefault(small.flat.names[nm], {})[wl_str[c]] = v
+    want_nz = {k: v for k, v in want.items() if v}
+    ok = got == want_nz and [(wl_str[c], h) for c, h in zip(out['cells'].tolist(), out['cell_hits'].tolist())] == list(wbc.items())
+    return {'records': n_records, 'bundles': st['bundles'], 'identical': bool(ok)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--records', type=int, default=50_000_000)
@@ -74,25 +98,8 @@ def main():
     eng.upload_index(ann.flat)
     res = {}
     if args.check:
-        from oracle import te_oracle as orc
-        small = synth.make_annotation('hg38', scale=0.01)
-        eng.upload_index(small.flat)
-        arrays, wl, tables = synth.make_sc_arrays(small, args.check, n_cells=40, n_whitelist=5000, seed=11)
-        thr = max(1000, args.check // 8)
-        out, st, _, _ = run(eng, arrays, wl, tables, 25, args.strand, thr)
-        wl_str = [bytes(r).rstrip(b'\0').decode() for r in wl]
-        feats = [{'chr': small.flat.chrom_keys[c], 'left': int(l), 'right': int(r), 'strand': '+-'[(m >> 29) & 1],
-                  'name': 'x', 'type': 'TE' if ((m >> 26) & 7) == 2 else 'protein_coding', 'ensg': small.flat.names[m & ((1 << 26) - 1)]}
-                 for c, l, r, m in zip(small.flat.chrom_id.tolist(), small.flat.left.tolist(), small.flat.right.tolist(), small.flat.meta.tolist())]
-        recs = synth.sc_arrays_to_records(arrays, tables[0])
-        want, wbc, _ = orc.sc_count(feats, recs, wl_str, 25, strand=args.strand, bundle_threshold=thr)
-        got = {}
-        for c, nm, v in zip(out['coo_cell'].tolist(), out['coo_name'].tolist(), out['coo_count'].tolist()):
-            got.setdefault(small.flat.names[nm], {})[wl_str[c]] = v
-        want_nz = {k: v for k, v in want.items() if v}
-        ok = got == want_nz and [(wl_str[c], h) for c, h in zip(out['cells'].tolist(), out['cell_hits'].tolist())] == list(wbc.items())
-        res['oracle_check'] = {'records': args.check, 'bundles': st['bundles'], 'identical': bool(ok)}
-        if not ok:
+        res['oracle_check'] = oracle_check(eng, ann, args.check, args.strand)
+        if not res['oracle_check']['identical']:
             print(json.dumps(res))
             sys.exit('PARITY FAILURE in the reduced-size single-cell check')
         eng.upload_index(ann.flat)
