@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--traffic', default=None, help='HBM bytes per launch from rocprofv3 --pmc passes; default: profiles/traffic.json entry of this workload')
     ap.add_argument('--no-host-stream', action='store_true', help='skip the PCIe-inclusive measurement')
     ap.add_argument('--legs', default='all', help="'all' (default at N=1), 'headline', or a comma list of: cpu,pcie,e2e,sc,secondary")
+    ap.add_argument('--details', default=None, help='also write the un-abridged result (every leg with its samples, stats and timings) to this file')
     ap.add_argument('--e2e-records', type=int, default=16_000_000)
     ap.add_argument('--sc-records', type=int, default=50_000_000)
     args = ap.parse_args()
@@ -175,7 +176,10 @@ def main():
             out['secondary'] = leg(secondary, ann, eng, args)
         if legs:
             out['config']['legs_s'] = round(time.time() - t_legs, 1)
-        print(json.dumps(out))
+        if args.details:
+            with open(args.details, 'w') as fh:
+                json.dump(out, fh, indent=1)
+        print(json.dumps(compact(out)))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
@@ -227,6 +231,42 @@ class BulkRun:
         self.dev = self.ptrs = None
         import torch
         torch.cuda.empty_cache()
+
+
+def compact(out):
+    """The one line the driver parses stays short: every leg keeps its numbers, long texts and stat
+    dumps go to --details."""
+    o = dict(out)
+    o['config'] = {k: v for k, v in out['config'].items() if k != 'index'}
+    o['config']['index'] = {k: out['config']['index'][k] for k in ('n_entries', 'n_bins')}
+    pick = lambda d, keys: {k: d[k] for k in keys if k in d}  # noqa: E731
+    rl = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'gpu_stream_ms', 'launch_ms_min_median_max')
+    for k in ('cpu_baseline', 'cpu_baseline_c_1core', 'cpu_baseline_c_allcores'):
+        if k in o and 'error' not in o[k]:
+            o[k] = pick(o[k], ('value', 'unit', 'cores', 'kind'))
+            o[k]['sample'] = out[k]['sample'].split(',')[0][:90]
+    if 'pcie_inclusive' in o:
+        o['pcie_inclusive'] = pick(o['pcie_inclusive'], ('value', 'unit', 'GB_per_s_over_pcie'))
+    e = out.get('end_to_end_from_bam')
+    if e and 'error' not in e:
+        c = {'value': e['value'], 'unit': e['unit'], 'host_decoder_16_threads': e['illumina_host_decoder']['Mrecords_per_s_decode_and_count']}
+        for payload in ('illumina', 'random'):
+            r = e[payload]
+            c[payload] = {'records': r['records'], 'bam_MB': r['bam_MB'], 'Mrecords_per_s': r['Mrecords_per_s_decode_and_count'],
+                          'first_run_s': r['first_run']['decode_and_count'], 'warm_run_s': r['warm_run']['decode_and_count'],
+                          'with_index_load_and_tsv_s': r['warm_run']['total'], 'seconds': r['decode']['seconds'] if r.get('decode') else None,
+                          'tsv_ok': r['tsv_identical_to_oracle_formatting']}
+        o['end_to_end_from_bam'] = c
+    sc = out.get('single_cell')
+    if sc and 'error' not in sc:
+        o['single_cell'] = {'value': sc['value'], 'unit': sc['unit'], 'records': sc['records'], 'seconds': sc['seconds'],
+                            'bundles': sc['stats']['bundles'], 'oracle_check_identical': sc['oracle_check']['identical'],
+                            'roofline': pick(sc['roofline'], rl)}
+    sec = out.get('secondary')
+    if sec and 'error' not in sec:
+        o['secondary'] = {k: {'value': v['value'], 'unit': v['unit'], 'ms_per_step': v['ms_per_step'], 'roofline': pick(v['roofline'], rl)}
+                          for k, v in sec.items()}
+    return o
 
 
 def leg(fn, *a):
@@ -437,12 +477,13 @@ def secondary(ann, eng, args):
         counts, st = run.count(5)
         dt = time.perf_counter() - t
         kernel_ms, launches = eng.bulk_kernel_time()
+        reduce_ms, launch_ms = eng.bulk_reduce_time(), eng.bulk_launch_times()
         single, _ = run.count(1)
         if not np.array_equal(counts, single * 5):
             raise SystemExit('PARITY FAILURE: linearity violated in ' + key)
         out[key] = {'value': round(run.n_units * 5 / dt / 1e6, 1), 'unit': 'Mreads/s', 'ms_per_step': round(dt / 5 * 1e3, 4),
                     'names': a.flat.n_names, 'assigned_frac': round(st['assigned'] / 5 / run.n_units, 4),
-                    'roofline': run.roofline(kernel_ms, launches, eng.bulk_reduce_time(), eng.bulk_launch_times(),
+                    'roofline': run.roofline(kernel_ms, launches, reduce_ms, launch_ms,
                                              traffic_for(None, genome, layout, order, run.n_units))}
         run.release()
     return out

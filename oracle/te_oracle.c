@@ -26,9 +26,6 @@ typedef struct {
     int64_t *chrom_nb;     /* number of buckets per chromosome */
     uint64_t *off;         /* CSR offsets */
     uint32_t *idx;         /* feature indices, in feature order inside a bucket */
-    uint64_t *stamp;       /* per-name "already counted for this unit" marks */
-    uint64_t *fstamp;      /* per-feature "already in loc_ids" marks */
-    uint64_t tick;
 } orc_index;
 
 static int64_t floordiv(int64_t a, int64_t b) {
@@ -40,7 +37,7 @@ static int64_t floordiv(int64_t a, int64_t b) {
 void orc_index_free(orc_index *ix) {
     if (!ix) return;
     free(ix->left); free(ix->right); free(ix->name); free(ix->cls); free(ix->chrom_base);
-    free(ix->chrom_nb); free(ix->off); free(ix->idx); free(ix->stamp); free(ix->fstamp);
+    free(ix->chrom_nb); free(ix->off); free(ix->idx);
     free(ix);
 }
 
@@ -73,8 +70,6 @@ orc_index *orc_index_build(uint64_t n, const int32_t *chrom, const int32_t *left
         for (int64_t b = lo < 0 ? 0 : lo; b < hi; ++b) ix->idx[cur[ix->chrom_base[chrom[i]] + b]++] = (uint32_t)i;
     }
     free(cur);
-    ix->stamp = calloc(n_names + 1, 8);
-    ix->fstamp = calloc(n + 1, 8);
     return ix;
 }
 
@@ -87,6 +82,9 @@ int orc_bulk_count(orc_index *ix, uint64_t n, const int32_t *chrom, const int32_
                    const uint16_t *flag, const uint8_t *mapq, int q, uint64_t *counts, uint64_t *stats) {
     uint32_t hitbuf_cap = 64, *hits = malloc(hitbuf_cap * 4);
     int crashed = 0;
+    /* the "already seen in this read" marks are private to the call, so that several threads may count
+     * disjoint unit ranges against one index (bench.py's all-cores baseline) */
+    uint64_t *stamp = calloc((size_t)ix->n_names + 1, 8), *fstamp = calloc((size_t)ix->n_features + 1, 8), tick = 0;
     for (uint64_t u = 0; u < n; ++u) {
         if (flag[u] & 0x604) { stats[3]++; continue; }
         if ((int)mapq[u] < q) { stats[1]++; continue; }
@@ -94,7 +92,7 @@ int orc_bulk_count(orc_index *ix, uint64_t n, const int32_t *chrom, const int32_
         if (c < 0 || (uint32_t)c >= ix->n_chrom) { stats[2]++; continue; }
         int64_t a = p1[u], b = p2[u];
         int64_t bk[2] = { floordiv(a - 1, BS), floordiv(b + 1, BS) };
-        uint64_t tick = ++ix->tick;
+        ++tick;
         uint32_t nh = 0, classes = 0;
         for (int k = 0; k < 2; ++k) {
             if (k == 1 && bk[1] == bk[0]) break;
@@ -102,8 +100,8 @@ int orc_bulk_count(orc_index *ix, uint64_t n, const int32_t *chrom, const int32_
             uint64_t g = ix->chrom_base[c] + (uint64_t)bk[k];
             for (uint64_t j = ix->off[g]; j < ix->off[g + 1]; ++j) {
                 uint32_t f = ix->idx[j];
-                if (ix->fstamp[f] == tick) continue;  /* loc_ids is a set */
-                ix->fstamp[f] = tick;
+                if (fstamp[f] == tick) continue;  /* loc_ids is a set */
+                fstamp[f] = tick;
                 int64_t gl = ix->left[f], gr = ix->right[f];
                 if ((a >= gl && a + 1 <= gr) || (b - 1 >= gl && b <= gr)) {
                     if (nh == hitbuf_cap) { hitbuf_cap *= 2; hits = realloc(hits, hitbuf_cap * 4); }
@@ -116,7 +114,7 @@ int orc_bulk_count(orc_index *ix, uint64_t n, const int32_t *chrom, const int32_
         if (classes & COUNTABLE) {
             for (uint32_t h = 0; h < nh; ++h) {
                 uint32_t nm = ix->name[hits[h]];
-                if (ix->stamp[nm] != tick) { ix->stamp[nm] = tick; counts[nm]++; }
+                if (stamp[nm] != tick) { stamp[nm] = tick; counts[nm]++; }
             }
         } else if (classes & ENHANCER) {
             crashed = 1;
@@ -125,5 +123,7 @@ int orc_bulk_count(orc_index *ix, uint64_t n, const int32_t *chrom, const int32_
         stats[0]++;
     }
     free(hits);
+    free(stamp);
+    free(fstamp);
     return crashed;
 }
