@@ -204,6 +204,38 @@ int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_cls, const i
 /* Part 1 (te_count.py:371-476).  Returns TEC_ENOCB / TEC_ENOUB where the reference asserts.
  * *n_cells_seen = number of barcodes with a non-zero raw count. */
 int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen);
+/* ---- part 1 in steps, and the hooks a multi-GPU caller needs --------------------------------------
+ * With several GPUs every rank decodes and filters its own slice of the file, then the survivors are
+ * dealt to the GPUs by barcode id (tec_sc_survivors_fetch / _replace through the caller's all-to-all), so
+ * that every (CB,UB) key and every cell row is local to one GPU.  What stays global is order-dependent:
+ *   - record ordinals: tec_sc_set_record_base adds the number of records in the slices before this one
+ *     (total_records = records in the whole file);
+ *   - the spill ("bundle") boundaries: the reference flushes when its dict holds 1e7 keys
+ *     (te_count.py:377), i.e. at the record that opens the bundle_keys-th NEW key since the last flush, in
+ *     file order.  tec_sc_epoch_marks collects this GPU's new-key records after `lower` (-1 = start);
+ *     the caller sums the counts over the GPUs and, while the sum reaches bundle_keys, finds the ordinal
+ *     with global rank bundle_keys by bisection on tec_sc_epoch_rank (one GPU: tec_sc_epoch_kth);
+ *   - the drop rule of the bundle reader (te_count.py:509-543) looks at the previous line of the whole
+ *     bundle: tec_sc_presence / tec_sc_part23_global carry the OR of all GPUs' (bundle, barcode) tables;
+ *   - the barcode selection (te_count.py:502) over the gathered tec_sc_part1_fetch rows.
+ * tec_sc_part1 / tec_sc_part23 run the same steps for a single GPU. */
+int tec_sc_set_record_base(tec_ctx* ctx, uint64_t base, uint64_t total_records);
+int tec_sc_survivors(tec_ctx* ctx, uint64_t* n);
+int tec_sc_survivors_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* u0, uint64_t* u1, uint64_t* u2, uint64_t* rec, int32_t* klass,
+                           int32_t* left, int32_t* rite);
+int tec_sc_survivors_replace(tec_ctx* ctx, uint64_t n, const uint32_t* bcid, const uint64_t* u0, const uint64_t* u1,
+                             const uint64_t* u2, const uint64_t* rec, const int32_t* klass, const int32_t* left,
+                             const int32_t* rite);
+int tec_sc_part1_sort(tec_ctx* ctx, uint64_t* n_keys);
+int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t* first_no_ub);
+int tec_sc_epoch_marks(tec_ctx* ctx, int64_t lower, uint64_t* n_marks);
+int tec_sc_epoch_rank(tec_ctx* ctx, uint64_t v, uint64_t* count_le);
+int tec_sc_epoch_kth(tec_ctx* ctx, uint64_t k, uint64_t* ordinal);
+int tec_sc_part1_finish(tec_ctx* ctx, uint32_t n_bounds, const uint64_t* bounds, uint64_t* n_cells_seen);
+int tec_sc_presence(tec_ctx* ctx, uint32_t n_bundles, uint8_t* present);
+int tec_sc_part23_global(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint32_t n_bundles,
+                         const uint8_t* present, uint64_t* kept_lines, uint64_t* n_cells_hit, uint64_t* n_coo);
+
 /* Barcodes seen (ascending id), their raw counts (self.barcodes of part 1) and the ordinal of the
  * record that first counted them (dict insertion order, for the stable sort at te_count.py:502). */
 int tec_sc_part1_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* count, uint64_t* first_seen);

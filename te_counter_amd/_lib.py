@@ -60,6 +60,18 @@ _SIGNATURES = {
     'tec_sc_begin': (C.c_int, [_p, C.c_int, C.c_int, C.c_uint32, _p, _u64, C.c_uint32, _p, _p]),
     'tec_sc_submit': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),
     'tec_sc_part1': (C.c_int, [_p, C.POINTER(_u64)]),
+    'tec_sc_set_record_base': (C.c_int, [_p, _u64, _u64]),
+    'tec_sc_survivors': (C.c_int, [_p, C.POINTER(_u64)]),
+    'tec_sc_survivors_fetch': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'tec_sc_survivors_replace': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'tec_sc_part1_sort': (C.c_int, [_p, C.POINTER(_u64)]),
+    'tec_sc_missing_tags': (C.c_int, [_p, C.POINTER(_u64), C.POINTER(_u64)]),
+    'tec_sc_epoch_marks': (C.c_int, [_p, C.c_int64, C.POINTER(_u64)]),
+    'tec_sc_epoch_rank': (C.c_int, [_p, _u64, C.POINTER(_u64)]),
+    'tec_sc_epoch_kth': (C.c_int, [_p, _u64, C.POINTER(_u64)]),
+    'tec_sc_part1_finish': (C.c_int, [_p, C.c_uint32, _p, C.POINTER(_u64)]),
+    'tec_sc_presence': (C.c_int, [_p, C.c_uint32, _p]),
+    'tec_sc_part23_global': (C.c_int, [_p, C.c_uint32, _p, C.c_uint32, _p, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     'tec_sc_part1_fetch': (C.c_int, [_p, _p, _p, _p]),
     'tec_sc_part23': (C.c_int, [_p, C.c_uint32, _p, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     'tec_sc_fetch': (C.c_int, [_p, _p, _p, _p, _p, _p]),

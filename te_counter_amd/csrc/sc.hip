@@ -86,13 +86,16 @@ struct tec_sc_state {
     dvec<uint32_t> b_live, b_scan, b_bcid;
     dvec<char> b_in, tmp;
     // sorted views (part 1)
-    dvec<uint32_t> perm, perm2, s_bcid, gid, s_epoch, headidx, cnt, first_seen;
-    dvec<uint64_t> k64a, k64b, s_u0, s_u1, s_u2;
+    dvec<uint32_t> perm, perm2, s_bcid, gid, s_epoch, headidx, cnt;
+    dvec<unsigned long long> first_seen;
+    dvec<uint64_t> k64a, k64b, s_u0, s_u1, s_u2, s_rec, marks;
     dvec<uint32_t> k32a, k32b;
     dvec<int32_t> s_klass, s_left, s_rite;
     dvec<uint8_t> ghead, ihead, counted;
     uint32_t n_groups = 0, n_epochs = 1;
-    bool part1_done = false;
+    bool part1_done = false, sorted = false;
+    uint64_t rec_base = 0, max_rec = 0, n_marks = 0;  // global ordinal of this context's first record; largest ordinal anywhere
+    std::vector<uint64_t> bounds;                      // flush boundaries (global record ordinals)
     std::vector<uint32_t> cells_seen;
     std::vector<uint64_t> cells_count, cells_first;
     // results
@@ -277,28 +280,48 @@ __global__ void ghead_kernel(uint64_t n, const uint32_t* __restrict__ bc, const 
     ghead32[i] = h;
 }
 
-// Marks, in file-order (ordinal) space, the first record of every key after ordinal `lower`.
-__global__ void epoch_mark_kernel(uint64_t n, const uint32_t* __restrict__ ord, const uint8_t* __restrict__ ghead,
-                                  long long lower, uint32_t* mark_by_ord) {
+// Marks (in key-sorted space; `rec` = global record ordinals, ascending inside a key) the first record
+// of every key after record `lower`: the records that create a NEW dict entry once the reference has
+// flushed at `lower` (te_count.py:377-390, 464-473).
+__global__ void epoch_mark_kernel(uint64_t n, const uint64_t* __restrict__ rec, const uint8_t* __restrict__ ghead,
+                                  long long lower, uint32_t* mark) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long o = ord[i];
-    const bool m = o > lower && (ghead[i] || (long long)ord[i - 1] <= lower);
-    mark_by_ord[o] = m ? 1u : 0u;
+    const long long o = (long long)rec[i];
+    const bool m = o > lower && (ghead[i] || (long long)rec[i - 1] <= lower);
+    mark[i] = m ? 1u : 0u;
 }
 
-__global__ void epoch_find_kernel(uint64_t n, const uint32_t* __restrict__ mark, const uint32_t* __restrict__ cum,
-                                  uint32_t target, unsigned long long* out) {
-    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < n && mark[o] && cum[o] == target) *out = o;
+__global__ void compact_rec_kernel(uint64_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan,
+                                   const uint64_t* __restrict__ rec, uint64_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[scan[i]] = rec[i];
 }
 
-__global__ void epoch_assign_kernel(uint64_t n, const uint32_t* __restrict__ ord, const uint32_t* __restrict__ bounds,
+// out[0] = number of sorted values <= v (one thread: a 40-step binary search)
+__global__ void upper_bound_kernel(const uint64_t* __restrict__ sorted, uint64_t n, uint64_t v, unsigned long long* out) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sorted[mid] <= v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[0] = lo;
+}
+
+__global__ void add_base_kernel(uint64_t n, uint64_t* rec, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rec[i] += base;
+}
+
+__global__ void epoch_assign_kernel(uint64_t n, const uint64_t* __restrict__ ord, const uint64_t* __restrict__ bounds,
                                     uint32_t n_bounds, uint32_t* epoch) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t lo = 0, hi = n_bounds;  // number of boundaries strictly below this ordinal
-    const uint32_t o = ord[i];
+    const uint64_t o = ord[i];
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if (bounds[mid] < o)
@@ -321,15 +344,15 @@ __global__ void ihead_kernel(uint64_t n, const uint8_t* __restrict__ ghead, cons
 // counted = a string is stored / the barcode counter bumps (te_count.py:457-473)
 __global__ void part1_count_kernel(uint64_t n, const uint8_t* __restrict__ ihead, const uint32_t* __restrict__ headidx,
                                    const int32_t* __restrict__ klass, const uint32_t* __restrict__ bc,
-                                   const uint32_t* __restrict__ ord, uint8_t* counted, uint32_t* cnt,
-                                   uint32_t* first_seen) {
+                                   const uint64_t* __restrict__ ord, uint8_t* counted, uint32_t* cnt,
+                                   unsigned long long* first_seen) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool c = ihead[i] || klass[i] != klass[headidx[i]];
     counted[i] = c;
     if (c) {
         atomicAdd(&cnt[bc[i]], 1u);
-        atomicMin(&first_seen[bc[i]], ord[i]);
+        atomicMin(&first_seen[bc[i]], (unsigned long long)ord[i]);
     }
 }
 
@@ -349,11 +372,37 @@ __global__ void scatter_sel_kernel(uint32_t n, const uint32_t* __restrict__ sel_
     if (i < n) sel[sel_ids[i]] = 1u;
 }
 
-// The bundle reader's drop rule (te_count.py:509-543), one thread per bundle line.
+// Which (bundle, barcode) pairs have lines at all: present[e * n_wl + b] = 1.
+__global__ void presence_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_rec, const uint32_t* __restrict__ bc,
+                                const uint32_t* __restrict__ epoch, uint32_t n_wl, uint32_t* present) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_lines) return;
+    const uint32_t i = line_rec[j];
+    present[(size_t)epoch[i] * n_wl + bc[i]] = 1u;
+}
+
+// val[e * n_wl + b] = e * (n_wl + 1) + b + 1 where (e, b) has lines, else 0.  An inclusive max-scan over
+// the whole table then holds, at slot (e, b), the mark of the largest barcode <= b with lines in bundle
+// e -- or a mark of an EARLIER bundle (recognisable by its quotient) if bundle e has none up to b.
+__global__ void presence_mark_kernel(uint64_t n, const uint32_t* __restrict__ present, uint32_t n_wl, uint32_t* val) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint32_t e = (uint32_t)(x / n_wl), b = (uint32_t)(x % n_wl);
+    val[x] = present[x] ? e * (n_wl + 1u) + b + 1u : 0u;
+}
+
+// The bundle reader's drop rule (te_count.py:509-543), one thread per bundle line.  A bundle's lines
+// are sorted by (barcode, UMI); with the cells dealt over several GPUs a line's predecessor may live on
+// another GPU, so the rule is evaluated against the GLOBAL set of (bundle, barcode) pairs that have
+// lines (pred, from the all-reduced presence table): a line is kept iff its barcode is selected and
+//   - the previous line of the bundle has the same barcode, or
+//   - there is an earlier barcode p with lines in this bundle (else this is the bundle's first line,
+//     which the reader never emits) and no selected barcode lies in [p, barcode).
 __global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_rec, const uint32_t* __restrict__ bc,
                             const uint32_t* __restrict__ epoch, const uint32_t* __restrict__ sel,
-                            const uint32_t* __restrict__ selprefix, const uint32_t* __restrict__ gid, uint8_t* kept_rec,
-                            uint32_t* firstkept, unsigned long long* n_kept) {
+                            const uint32_t* __restrict__ selprefix, const uint32_t* __restrict__ gid,
+                            const uint32_t* __restrict__ pred, uint32_t n_wl, uint8_t* kept_rec, uint32_t* firstkept,
+                            unsigned long long* n_kept) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t tally_lds[1];
     BlockTally<1> tally{tally_lds};
@@ -361,9 +410,21 @@ __global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_
     bool k = false;
     if (j < n_lines) {
         const uint32_t i = line_rec[j];
-        if (j > 0) {
-            const uint32_t p = line_rec[j - 1];
-            if (epoch[p] == epoch[i] && sel[bc[i]]) k = bc[p] == bc[i] || selprefix[bc[i]] == selprefix[bc[p]];
+        const uint32_t b = bc[i], e = epoch[i];
+        if (sel[b]) {
+            bool same = false;
+            if (j > 0) {
+                const uint32_t p = line_rec[j - 1];
+                same = epoch[p] == e && bc[p] == b;
+            }
+            if (same) {
+                k = true;
+            } else {
+                // the previous barcode with lines in this bundle (see presence_mark_kernel)
+                const uint32_t v = b ? pred[(size_t)e * n_wl + b - 1u] : 0u;
+                const bool has = v != 0u && v / (n_wl + 1u) == e;
+                k = has && selprefix[b] == selprefix[v - e * (n_wl + 1u) - 1u];
+            }
         }
         kept_rec[i] = k;
         if (k) atomicMin(&firstkept[gid[i]], i);
@@ -578,6 +639,7 @@ void sc_free(tec_sc_state* s) {
     s->headidx.release(); s->cnt.release(); s->first_seen.release(); s->k64a.release(); s->k64b.release();
     s->s_u0.release(); s->s_u1.release(); s->s_u2.release(); s->k32a.release(); s->k32b.release();
     s->s_klass.release(); s->s_left.release(); s->s_rite.release(); s->ghead.release(); s->ihead.release();
+    s->s_rec.release(); s->marks.release();
     s->counted.release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -759,31 +821,18 @@ extern "C" int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_c
     return sc_ingest(ctx, s, n, d_cls, d_pos, d_end, d_flag, d_mapq, d_cb24, d_ub24, d_tagflags);
 }
 
-extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
-    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part1: call tec_sc_begin first");
-    tec_sc_state* s = ctx->sc;
-    if (s->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part1: already done");
-    SC_HIP(hipSetDevice(ctx->device));
+namespace {
+
+// Part 1, step 1: stable LSD radix sort of a permutation by (bcid, u0, u1, u2); sorted views; key heads.
+int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
     hipStream_t st = ctx->s_compute;
     SC_HIP(hipStreamSynchronize(st));
     SC_HIP(hipMemcpy(s->h_stat, s->stat.p, sizeof s->h_stat, hipMemcpyDeviceToHost));
-    PhaseTimer timer(ctx, s);
-    s->part1_done = true;
-    s->cells_seen.clear();
-    s->cells_count.clear();
-    s->cells_first.clear();
-    if (n_cells_seen) *n_cells_seen = 0;
-    // the reference dies at the first record (file order) that lacks a tag
-    if (s->h_stat[ST_NOCB] != ~0ull || s->h_stat[ST_NOUB] != ~0ull) {
-        if (s->h_stat[ST_NOCB] < s->h_stat[ST_NOUB])
-            return tec_fail(ctx, TEC_ENOCB, "CB or CR tag not found! (record %llu)", s->h_stat[ST_NOCB]);
-        return tec_fail(ctx, TEC_ENOUB, "UB or UR tag not found! (record %llu)", s->h_stat[ST_NOUB]);
-    }
+    s->sorted = true;
+    s->bounds.clear();
     const uint64_t N = s->n_live;
     if (N == 0) return TEC_OK;
     const unsigned g = grid_for(N);
-
-    // ---- stable LSD radix sort of a permutation by (bcid, u0, u1, u2)
     SC_HIP(s->perm.reserve(N));
     SC_HIP(s->perm2.reserve(N));
     SC_HIP(s->k64a.reserve(N));
@@ -814,6 +863,7 @@ extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
     SC_HIP(s->s_u0.reserve(N));
     SC_HIP(s->s_u1.reserve(N));
     SC_HIP(s->s_u2.reserve(N));
+    SC_HIP(s->s_rec.reserve(N));
     SC_HIP(s->s_klass.reserve(N));
     SC_HIP(s->s_left.reserve(N));
     SC_HIP(s->s_rite.reserve(N));
@@ -821,6 +871,7 @@ extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u0.p, s->s_u0.p);
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u1.p, s->s_u1.p);
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u2.p, s->s_u2.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->rec.p, s->s_rec.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->klass.p, s->s_klass.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->left.p, s->s_left.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->rite.p, s->s_rite.p);
@@ -835,63 +886,81 @@ extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
     SC_HIP(hipMemcpyAsync(&last_gid, s->gid.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
     SC_HIP(hipStreamSynchronize(st));
     s->n_groups = last_gid;  // inclusive scan of heads: the last value is the number of keys
-    // gid = scan - 1 is only used as an array index: keep scan value and subtract at use sites
-    // ---- epochs (te_count.py:377-390): the flush fires once len(umis) has reached bundle_keys
-    std::vector<uint32_t> bounds;
-    if ((uint64_t)s->n_groups >= s->bundle_keys) {
-        long long lower = -1;
-        unsigned long long* d_found = s->stat.p + ST_N - 1;  // scratch word (ST_NOSTRAND is reset below)
-        for (;;) {
-            hipLaunchKernelGGL(epoch_mark_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->ghead.p, lower, s->k32a.p);
-            rc = scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, true, rocprim::plus<uint32_t>());
-            if (rc) return rc;
-            uint32_t total = 0;
-            SC_HIP(hipMemcpyAsync(&total, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
-            SC_HIP(hipStreamSynchronize(st));
-            if ((uint64_t)total < s->bundle_keys) break;
-            const unsigned long long none = ~0ull;
-            SC_HIP(hipMemcpyAsync(d_found, &none, 8, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(epoch_find_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p,
-                               (uint32_t)s->bundle_keys, d_found);
-            unsigned long long found = none;
-            SC_HIP(hipMemcpyAsync(&found, d_found, 8, hipMemcpyDeviceToHost, st));
-            SC_HIP(hipStreamSynchronize(st));
-            if (found == none) return tec_fail(ctx, TEC_EHIP, "tec_sc_part1: epoch boundary not found");
-            bounds.push_back((uint32_t)found);
-            lower = (long long)found;
-            if (bounds.size() > N / s->bundle_keys + 2) return tec_fail(ctx, TEC_EHIP, "tec_sc_part1: epoch loop runaway");
-        }
-        const unsigned long long zero = 0;
-        SC_HIP(hipMemcpyAsync(d_found, &zero, 8, hipMemcpyHostToDevice, st));
-    }
+    return TEC_OK;
+}
+
+// Part 1, step 2 (repeated): the records that open a NEW (CB,UB) dict entry after record `lower` -- their
+// ordinals, ascending, stay in s->marks.  The reference flushes once such entries number bundle_keys
+// (te_count.py:377): with the cells dealt over several GPUs the bundle_keys-th one is found by the
+// caller over all GPUs' marks (tec_sc_epoch_rank); on one GPU it is marks[bundle_keys - 1].
+int sc_epoch_marks(tec_ctx* ctx, tec_sc_state* s, long long lower, uint64_t* n_marks) {
+    hipStream_t st = ctx->s_compute;
+    const uint64_t N = s->n_live;
+    *n_marks = 0;
+    s->n_marks = 0;
+    if (N == 0) return TEC_OK;
+    const unsigned g = grid_for(N);
+    hipLaunchKernelGGL(epoch_mark_kernel, dim3(g), dim3(kB), 0, st, N, s->s_rec.p, s->ghead.p, lower, s->k32a.p);
+    int rc = scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, false, rocprim::plus<uint32_t>());
+    if (rc) return rc;
+    uint32_t ls = 0, lf = 0;
+    SC_HIP(hipMemcpyAsync(&ls, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(&lf, s->k32a.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    const uint64_t m = (uint64_t)ls + lf;
+    s->n_marks = m;
+    *n_marks = m;
+    if (!m) return TEC_OK;
+    SC_HIP(s->k64a.reserve(std::max<uint64_t>(N, m)));
+    SC_HIP(s->marks.reserve(m));
+    hipLaunchKernelGGL(compact_rec_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p, s->s_rec.p, s->k64a.p);
+    size_t bytes = 0;
+    SC_HIP(rocprim::radix_sort_keys(nullptr, bytes, s->k64a.p, s->marks.p, m, 0, bits_for(s->max_rec + 1), st));
+    SC_HIP(s->tmp.reserve(bytes));
+    SC_HIP(rocprim::radix_sort_keys(s->tmp.p, bytes, s->k64a.p, s->marks.p, m, 0, bits_for(s->max_rec + 1), st));
+    return TEC_OK;
+}
+
+// Part 1, step 3: bundles from the flush boundaries, (bundle, key) instances, duplicates vs extra
+// strings, per-barcode counts and first-seen ordinals.
+int sc_part1_finish(tec_ctx* ctx, tec_sc_state* s, const std::vector<uint64_t>& bounds) {
+    hipStream_t st = ctx->s_compute;
+    const uint64_t N = s->n_live;
+    s->bounds = bounds;
     s->n_epochs = (uint32_t)bounds.size() + 1;
+    s->part1_done = true;
+    s->cells_seen.clear();
+    s->cells_count.clear();
+    s->cells_first.clear();
+    if (N == 0) return TEC_OK;
+    const unsigned g = grid_for(N);
     SC_HIP(s->s_epoch.reserve(N));
     if (bounds.empty()) {
         SC_HIP(hipMemsetAsync(s->s_epoch.p, 0, N * 4, st));
     } else {
-        SC_HIP(s->k32b.reserve(std::max<size_t>(N, bounds.size())));
-        SC_HIP(hipMemcpyAsync(s->k32b.p, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(epoch_assign_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->k32b.p, (uint32_t)bounds.size(),
+        SC_HIP(s->k64b.reserve(std::max<size_t>(N, bounds.size())));
+        SC_HIP(hipMemcpyAsync(s->k64b.p, bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(epoch_assign_kernel, dim3(g), dim3(kB), 0, st, N, s->s_rec.p, s->k64b.p, (uint32_t)bounds.size(),
                            s->s_epoch.p);
         SC_HIP(hipStreamSynchronize(st));
     }
-    // ---- (epoch, key) instances, duplicates vs extra strings, per-barcode counts
     SC_HIP(s->ihead.reserve(N));
     SC_HIP(s->headidx.reserve(N));
     SC_HIP(s->counted.reserve(N));
     hipLaunchKernelGGL(ihead_kernel, dim3(g), dim3(kB), 0, st, N, s->ghead.p, s->s_epoch.p, s->ihead.p, s->k32a.p);
-    rc = scan_u32(ctx, s, s->k32a.p, s->headidx.p, N, true, rocprim::maximum<uint32_t>());
+    int rc = scan_u32(ctx, s, s->k32a.p, s->headidx.p, N, true, rocprim::maximum<uint32_t>());
     if (rc) return rc;
     SC_HIP(s->cnt.reserve(s->n_wl));
     SC_HIP(s->first_seen.reserve(s->n_wl));
     SC_HIP(hipMemsetAsync(s->cnt.p, 0, (size_t)s->n_wl * 4, st));
-    SC_HIP(hipMemsetAsync(s->first_seen.p, 0xFF, (size_t)s->n_wl * 4, st));
+    SC_HIP(hipMemsetAsync(s->first_seen.p, 0xFF, (size_t)s->n_wl * 8, st));
     hipLaunchKernelGGL(part1_count_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->headidx.p, s->s_klass.p, s->s_bcid.p,
-                       s->perm.p, s->counted.p, s->cnt.p, s->first_seen.p);
+                       s->s_rec.p, s->counted.p, s->cnt.p, s->first_seen.p);
     SC_HIP(hipGetLastError());
-    std::vector<uint32_t> hc(s->n_wl), hf(s->n_wl);
+    std::vector<uint32_t> hc(s->n_wl);
+    std::vector<unsigned long long> hf(s->n_wl);
     SC_HIP(hipMemcpyAsync(hc.data(), s->cnt.p, (size_t)s->n_wl * 4, hipMemcpyDeviceToHost, st));
-    SC_HIP(hipMemcpyAsync(hf.data(), s->first_seen.p, (size_t)s->n_wl * 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(hf.data(), s->first_seen.p, (size_t)s->n_wl * 8, hipMemcpyDeviceToHost, st));
     SC_HIP(hipStreamSynchronize(st));
     for (uint32_t c = 0; c < s->n_wl; ++c)
         if (hc[c]) {
@@ -899,6 +968,222 @@ extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
             s->cells_count.push_back(hc[c]);
             s->cells_first.push_back(hf[c]);
         }
+    return TEC_OK;
+}
+
+int sc_check_open(tec_ctx* ctx, const char* who, bool need_sorted) {
+    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "%s: call tec_sc_begin first", who);
+    if (ctx->sc->part1_done) return tec_fail(ctx, TEC_ESTATE, "%s: part 1 is already finished", who);
+    if (need_sorted && !ctx->sc->sorted) return tec_fail(ctx, TEC_ESTATE, "%s: call tec_sc_part1_sort first", who);
+    return TEC_OK;
+}
+
+}  // namespace
+
+// ---- the survivors of this GPU's records, for the multi-GPU exchange (cells are dealt to GPUs by
+// barcode id, so every (CB,UB) key and every cell row is then local to one GPU)
+extern "C" int tec_sc_survivors(tec_ctx* ctx, uint64_t* n) {
+    if (!ctx || !ctx->sc || !n) return tec_fail(ctx, TEC_ESTATE, "tec_sc_survivors: call tec_sc_begin first");
+    *n = ctx->sc->n_live;
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_survivors_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* u0, uint64_t* u1, uint64_t* u2, uint64_t* rec,
+                                      int32_t* klass, int32_t* left, int32_t* rite) {
+    int rc = sc_check_open(ctx, "tec_sc_survivors_fetch", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    const uint64_t n = s->n_live;
+    if (!n) return TEC_OK;
+    if (!bcid || !u0 || !u1 || !u2 || !rec || !klass || !left || !rite) return tec_fail(ctx, TEC_EINVAL, "tec_sc_survivors_fetch: NULL array");
+    SC_HIP(hipSetDevice(ctx->device));
+    SC_HIP(hipStreamSynchronize(ctx->s_compute));
+    SC_HIP(hipMemcpy(bcid, s->bcid.p, n * 4, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(u0, s->u0.p, n * 8, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(u1, s->u1.p, n * 8, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(u2, s->u2.p, n * 8, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(rec, s->rec.p, n * 8, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(klass, s->klass.p, n * 4, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(left, s->left.p, n * 4, hipMemcpyDeviceToHost));
+    SC_HIP(hipMemcpy(rite, s->rite.p, n * 4, hipMemcpyDeviceToHost));
+    return TEC_OK;
+}
+
+// Replaces the survivor set (rows in any order: they are sorted by record ordinal on the device, which
+// is the file order every later step relies on).
+extern "C" int tec_sc_survivors_replace(tec_ctx* ctx, uint64_t n, const uint32_t* bcid, const uint64_t* u0, const uint64_t* u1,
+                                        const uint64_t* u2, const uint64_t* rec, const int32_t* klass, const int32_t* left,
+                                        const int32_t* rite) {
+    int rc = sc_check_open(ctx, "tec_sc_survivors_replace", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (s->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_survivors_replace: after tec_sc_part1_sort");
+    if (n && (!bcid || !u0 || !u1 || !u2 || !rec || !klass || !left || !rite)) return tec_fail(ctx, TEC_EINVAL, "tec_sc_survivors_replace: NULL array");
+    if (n >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_survivors_replace: more than 2^32 rows");
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    SC_HIP(hipStreamSynchronize(st));
+    unsigned long long ors[3] = {0, 0, 0}, max_rec = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        ors[0] |= u0[i];
+        ors[1] |= u1[i];
+        ors[2] |= u2[i];
+        if (rec[i] > max_rec) max_rec = rec[i];
+    }
+    if (max_rec + 1 > s->max_rec) s->max_rec = max_rec + 1;
+    SC_HIP(hipMemcpy(s->stat.p + ST_OR0, ors, sizeof ors, hipMemcpyHostToDevice));
+    s->n_live = n;
+    if (!n) return TEC_OK;
+    SC_HIP(s->bcid.reserve(n)); SC_HIP(s->u0.reserve(n)); SC_HIP(s->u1.reserve(n)); SC_HIP(s->u2.reserve(n));
+    SC_HIP(s->rec.reserve(n)); SC_HIP(s->klass.reserve(n)); SC_HIP(s->left.reserve(n)); SC_HIP(s->rite.reserve(n));
+    SC_HIP(s->perm.reserve(n)); SC_HIP(s->perm2.reserve(n)); SC_HIP(s->k64a.reserve(n)); SC_HIP(s->k64b.reserve(n));
+    SC_HIP(s->k32a.reserve(n));
+    const unsigned g = grid_for(n);
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, n, s->perm.p);
+    SC_HIP(hipMemcpyAsync(s->k64a.p, rec, n * 8, hipMemcpyHostToDevice, st));
+    rc = sort_pairs(ctx, s, s->k64a.p, s->rec.p, s->perm.p, s->perm2.p, n, 0, bits_for(max_rec + 1));
+    if (rc) return rc;
+    // the other columns follow the permutation (through the two scratch columns)
+    auto col64 = [&](const uint64_t* h, uint64_t* d) -> int {
+        SC_HIP(hipMemcpyAsync(s->k64a.p, h, n * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->k64a.p, d);
+        return TEC_OK;
+    };
+    auto col32 = [&](const void* h, void* d) -> int {
+        SC_HIP(hipMemcpyAsync(s->k32a.p, h, n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->k32a.p, static_cast<uint32_t*>(d));
+        return TEC_OK;
+    };
+    if ((rc = col64(u0, s->u0.p)) || (rc = col64(u1, s->u1.p)) || (rc = col64(u2, s->u2.p))) return rc;
+    if ((rc = col32(bcid, s->bcid.p)) || (rc = col32(klass, s->klass.p)) || (rc = col32(left, s->left.p)) || (rc = col32(rite, s->rite.p))) return rc;
+    SC_HIP(hipStreamSynchronize(st));
+    return TEC_OK;
+}
+
+// ---- part 1 in steps (multi-GPU callers; tec_sc_part1 below runs them for one GPU)
+extern "C" int tec_sc_set_record_base(tec_ctx* ctx, uint64_t base, uint64_t total_records) {
+    int rc = sc_check_open(ctx, "tec_sc_set_record_base", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (s->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_set_record_base: after tec_sc_part1_sort");
+    SC_HIP(hipSetDevice(ctx->device));
+    if (base && s->n_live) hipLaunchKernelGGL(add_base_kernel, dim3(grid_for(s->n_live)), dim3(kB), 0, ctx->s_compute, s->n_live, s->rec.p, base);
+    SC_HIP(hipGetLastError());
+    s->rec_base += base;
+    s->max_rec = std::max<uint64_t>(total_records, s->rec_base + s->n_seen);
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_part1_sort(tec_ctx* ctx, uint64_t* n_keys) {
+    int rc = sc_check_open(ctx, "tec_sc_part1_sort", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    SC_HIP(hipSetDevice(ctx->device));
+    if (s->max_rec < s->rec_base + s->n_seen) s->max_rec = s->rec_base + s->n_seen;
+    PhaseTimer timer(ctx, s);
+    rc = sc_part1_sort(ctx, s);
+    if (rc) return rc;
+    if (n_keys) *n_keys = s->n_groups;
+    return TEC_OK;
+}
+
+/* ordinals (ST_NOCB / ST_NOUB) of the first record that lacks a barcode / UMI tag, ~0 if none: the
+ * reference dies at the smaller one (te_count.py:409, 426); valid after tec_sc_part1_sort */
+extern "C" int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t* first_no_ub) {
+    if (!ctx || !ctx->sc || !ctx->sc->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_missing_tags: call tec_sc_part1_sort first");
+    tec_sc_state* s = ctx->sc;
+    const unsigned long long none = ~0ull;
+    if (first_no_cb) *first_no_cb = s->h_stat[ST_NOCB] == none ? none : s->h_stat[ST_NOCB] + s->rec_base;
+    if (first_no_ub) *first_no_ub = s->h_stat[ST_NOUB] == none ? none : s->h_stat[ST_NOUB] + s->rec_base;
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_epoch_marks(tec_ctx* ctx, int64_t lower, uint64_t* n_marks) {
+    int rc = sc_check_open(ctx, "tec_sc_epoch_marks", true);
+    if (rc) return rc;
+    if (!n_marks) return tec_fail(ctx, TEC_EINVAL, "tec_sc_epoch_marks: NULL argument");
+    SC_HIP(hipSetDevice(ctx->device));
+    PhaseTimer timer(ctx, ctx->sc);
+    return sc_epoch_marks(ctx, ctx->sc, lower, n_marks);
+}
+
+extern "C" int tec_sc_epoch_rank(tec_ctx* ctx, uint64_t v, uint64_t* count_le) {
+    int rc = sc_check_open(ctx, "tec_sc_epoch_rank", true);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (!count_le) return tec_fail(ctx, TEC_EINVAL, "tec_sc_epoch_rank: NULL argument");
+    *count_le = 0;
+    if (!s->n_marks) return TEC_OK;
+    SC_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d = s->stat.p + ST_N - 1;  // scratch word (ST_NOSTRAND is reset before part 3)
+    hipLaunchKernelGGL(upper_bound_kernel, dim3(1), dim3(1), 0, ctx->s_compute, s->marks.p, s->n_marks, v, d);
+    unsigned long long h = 0;
+    SC_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->s_compute));
+    SC_HIP(hipStreamSynchronize(ctx->s_compute));
+    const unsigned long long zero = 0;
+    SC_HIP(hipMemcpyAsync(d, &zero, 8, hipMemcpyHostToDevice, ctx->s_compute));
+    *count_le = h;
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_epoch_kth(tec_ctx* ctx, uint64_t k, uint64_t* ordinal) {
+    int rc = sc_check_open(ctx, "tec_sc_epoch_kth", true);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (!ordinal || k == 0 || k > s->n_marks) return tec_fail(ctx, TEC_EINVAL, "tec_sc_epoch_kth: k out of range");
+    SC_HIP(hipSetDevice(ctx->device));
+    SC_HIP(hipMemcpy(ordinal, s->marks.p + (k - 1), 8, hipMemcpyDeviceToHost));
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_part1_finish(tec_ctx* ctx, uint32_t n_bounds, const uint64_t* bounds, uint64_t* n_cells_seen) {
+    int rc = sc_check_open(ctx, "tec_sc_part1_finish", true);
+    if (rc) return rc;
+    if (n_bounds && !bounds) return tec_fail(ctx, TEC_EINVAL, "tec_sc_part1_finish: NULL bounds");
+    SC_HIP(hipSetDevice(ctx->device));
+    PhaseTimer timer(ctx, ctx->sc);
+    rc = sc_part1_finish(ctx, ctx->sc, std::vector<uint64_t>(bounds, bounds + n_bounds));
+    if (rc) return rc;
+    if (n_cells_seen) *n_cells_seen = ctx->sc->cells_seen.size();
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
+    int rc = sc_check_open(ctx, "tec_sc_part1", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    SC_HIP(hipSetDevice(ctx->device));
+    if (n_cells_seen) *n_cells_seen = 0;
+    if (!s->sorted) {
+        rc = tec_sc_part1_sort(ctx, nullptr);
+        if (rc) return rc;
+    }
+    // the reference dies at the first record (file order) that lacks a tag
+    if (s->h_stat[ST_NOCB] != ~0ull || s->h_stat[ST_NOUB] != ~0ull) {
+        s->part1_done = true;
+        if (s->h_stat[ST_NOCB] < s->h_stat[ST_NOUB])
+            return tec_fail(ctx, TEC_ENOCB, "CB or CR tag not found! (record %llu)", s->h_stat[ST_NOCB]);
+        return tec_fail(ctx, TEC_ENOUB, "UB or UR tag not found! (record %llu)", s->h_stat[ST_NOUB]);
+    }
+    PhaseTimer timer(ctx, s);
+    // bundles (te_count.py:377-390): the flush fires once len(umis) has reached bundle_keys
+    std::vector<uint64_t> bounds;
+    if ((uint64_t)s->n_groups >= s->bundle_keys) {
+        long long lower = -1;
+        for (;;) {
+            uint64_t m = 0;
+            rc = sc_epoch_marks(ctx, s, lower, &m);
+            if (rc) return rc;
+            if (m < s->bundle_keys) break;
+            uint64_t b = 0;
+            SC_HIP(hipMemcpy(&b, s->marks.p + (s->bundle_keys - 1), 8, hipMemcpyDeviceToHost));
+            bounds.push_back(b);
+            lower = (long long)b;
+            if (bounds.size() > s->n_live / s->bundle_keys + 2) return tec_fail(ctx, TEC_EHIP, "tec_sc_part1: epoch loop runaway");
+        }
+    }
+    rc = sc_part1_finish(ctx, s, bounds);
+    if (rc) return rc;
     if (n_cells_seen) *n_cells_seen = s->cells_seen.size();
     return TEC_OK;
 }
@@ -913,8 +1198,88 @@ extern "C" int tec_sc_part1_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* count,
     return TEC_OK;
 }
 
+namespace {
+// Bundle lines = (bundle, key) instance heads in (bundle, barcode, UMI) order -> lines_out (device), count.
+int sc_lines(tec_ctx* ctx, tec_sc_state* s, dvec<uint32_t>& lines, dvec<uint32_t>& lkeys, dvec<uint32_t>& lkeys2,
+             dvec<uint32_t>& lines2, uint64_t* n_lines_out) {
+    hipStream_t st = ctx->s_compute;
+    const uint64_t N = s->n_live;
+    const unsigned g = grid_for(N);
+    SC_HIP(s->k32a.reserve(N));
+    SC_HIP(s->k32b.reserve(N));
+    hipLaunchKernelGGL(flag_from_u8_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->k32a.p);
+    int rc = scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, false, rocprim::plus<uint32_t>());
+    if (rc) return rc;
+    uint32_t ls = 0, lf = 0;
+    SC_HIP(hipMemcpyAsync(&ls, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(&lf, s->k32a.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    const uint64_t n_lines = (uint64_t)ls + lf;
+    *n_lines_out = n_lines;
+    SC_HIP(lines.reserve(n_lines));
+    hipLaunchKernelGGL(compact_idx_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p, lines.p);
+    if (s->n_epochs > 1) {
+        SC_HIP(lkeys.reserve(n_lines));
+        SC_HIP(lkeys2.reserve(n_lines));
+        SC_HIP(lines2.reserve(n_lines));
+        hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_epoch.p, lkeys.p);
+        rc = sort_pairs(ctx, s, lkeys.p, lkeys2.p, lines.p, lines2.p, n_lines, 0, bits_for(s->n_epochs));
+        if (rc) return rc;
+        std::swap(lines.p, lines2.p);
+        std::swap(lines.cap, lines2.cap);
+    }
+    return TEC_OK;
+}
+}  // namespace
+
+// Which (bundle, barcode) pairs have bundle lines on this GPU: present[e * n_whitelist + b] in {0, 1},
+// n_bundles * n_whitelist entries.  Multi-GPU callers OR the tables of all GPUs and hand the result to
+// tec_sc_part23_global (the drop rule looks at a line's predecessor in the WHOLE bundle).
+extern "C" int tec_sc_presence(tec_ctx* ctx, uint32_t n_bundles, uint8_t* present) {
+    if (!ctx || !ctx->sc || !ctx->sc->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_presence: finish part 1 first");
+    tec_sc_state* s = ctx->sc;
+    if (!present || n_bundles < s->n_epochs) return tec_fail(ctx, TEC_EINVAL, "tec_sc_presence: table too small");
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    const size_t cells = (size_t)n_bundles * s->n_wl;
+    memset(present, 0, cells);
+    if (s->n_live == 0) return TEC_OK;
+    dvec<uint32_t> lines, lkeys, lkeys2, lines2, pres;
+    auto cleanup = [&]() { lines.release(); lkeys.release(); lkeys2.release(); lines2.release(); pres.release(); };
+    uint64_t n_lines = 0;
+    int rc = sc_lines(ctx, s, lines, lkeys, lkeys2, lines2, &n_lines);
+    hipError_t e = rc ? hipSuccess : pres.reserve(cells);
+    if (!rc && e == hipSuccess) e = hipMemsetAsync(pres.p, 0, cells * 4, st);
+    if (!rc && e == hipSuccess) {
+        hipLaunchKernelGGL(presence_kernel, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
+                           s->n_wl, pres.p);
+        std::vector<uint32_t> h(cells);
+        e = hipMemcpy(h.data(), pres.p, cells * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (size_t i = 0; i < cells; ++i) present[i] = h[i] ? 1 : 0;
+    }
+    cleanup();
+    if (rc) return rc;
+    if (e != hipSuccess) return tec_fail(ctx, TEC_EHIP, "tec_sc_presence: %s", hipGetErrorString(e));
+    return TEC_OK;
+}
+
+static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint32_t n_bundles,
+                          const uint8_t* present_global, uint64_t* kept_lines, uint64_t* n_cells_hit, uint64_t* n_coo);
+
 extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint64_t* kept_lines,
                              uint64_t* n_cells_hit, uint64_t* n_coo) {
+    return sc_part23_impl(ctx, n_selected, selected_bcid, 0, nullptr, kept_lines, n_cells_hit, n_coo);
+}
+
+extern "C" int tec_sc_part23_global(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint32_t n_bundles,
+                                    const uint8_t* present, uint64_t* kept_lines, uint64_t* n_cells_hit, uint64_t* n_coo) {
+    if (!present) return tec_fail(ctx, TEC_EINVAL, "tec_sc_part23_global: NULL presence table");
+    return sc_part23_impl(ctx, n_selected, selected_bcid, n_bundles, present, kept_lines, n_cells_hit, n_coo);
+}
+
+static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* selected_bcid, uint32_t n_bundles,
+                          const uint8_t* present_global, uint64_t* kept_lines, uint64_t* n_cells_hit, uint64_t* n_coo) {
     if (!ctx || !ctx->sc || !ctx->sc->part1_done) return tec_fail(ctx, TEC_ESTATE, "tec_sc_part23: run tec_sc_part1 first");
     tec_sc_state* s = ctx->sc;
     SC_HIP(hipSetDevice(ctx->device));
@@ -932,7 +1297,7 @@ extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* 
             return tec_fail(ctx, TEC_EINVAL, "tec_sc_part23: selected barcodes must be ascending whitelist ids");
     const unsigned g = grid_for(N);
     // ---- selection mask and its exclusive prefix (number of selected ids below c)
-    dvec<uint32_t> sel, selprefix, lines, lkeys, lkeys2, lines2, firstkept, qflag, qscan, qrec, nemit, emoff, cellhits;
+    dvec<uint32_t> sel, selprefix, lines, lkeys, lkeys2, lines2, firstkept, qflag, qscan, qrec, nemit, emoff, cellhits, present, pred;
     dvec<uint8_t> kept_rec;
     dvec<uint64_t> keys, keys2, ukeys;
     dvec<unsigned long long> scal;
@@ -940,6 +1305,7 @@ extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* 
         sel.release(); selprefix.release(); lines.release(); lkeys.release(); lkeys2.release(); lines2.release();
         firstkept.release(); qflag.release(); qscan.release(); qrec.release(); nemit.release(); emoff.release();
         cellhits.release(); kept_rec.release(); keys.release(); keys2.release(); ukeys.release(); scal.release();
+        present.release(); pred.release();
     };
 #define SC_TRY(call)                         \
     do {                                     \
@@ -965,26 +1331,33 @@ extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* 
     hipLaunchKernelGGL(scatter_sel_kernel, dim3((n_selected + kB - 1) / kB), dim3(kB), 0, st, n_selected, s->k32a.p, sel.p);
     SC_RC(scan_u32(ctx, s, sel.p, selprefix.p, s->n_wl, false, rocprim::plus<uint32_t>()));
     // ---- bundle lines = instance heads in (epoch, barcode, UMI) order
-    SC_TRY(s->k32b.reserve(N));
-    hipLaunchKernelGGL(flag_from_u8_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->k32a.p);
-    SC_RC(scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, false, rocprim::plus<uint32_t>()));
-    uint32_t ls = 0, lf = 0;
-    SC_TRY(hipMemcpyAsync(&ls, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_TRY(hipMemcpyAsync(&lf, s->k32a.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_TRY(hipStreamSynchronize(st));
-    const uint64_t n_lines = (uint64_t)ls + lf;
-    SC_TRY(lines.reserve(n_lines));
-    hipLaunchKernelGGL(compact_idx_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p, lines.p);
-    if (s->n_epochs > 1) {
-        SC_TRY(lkeys.reserve(n_lines));
-        SC_TRY(lkeys2.reserve(n_lines));
-        SC_TRY(lines2.reserve(n_lines));
-        hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_epoch.p,
-                           lkeys.p);
-        SC_RC(sort_pairs(ctx, s, lkeys.p, lkeys2.p, lines.p, lines2.p, n_lines, 0, bits_for(s->n_epochs)));
-        std::swap(lines.p, lines2.p);
-        std::swap(lines.cap, lines2.cap);
+    uint64_t n_lines = 0;
+    SC_RC(sc_lines(ctx, s, lines, lkeys, lkeys2, lines2, &n_lines));
+    // ---- which (bundle, barcode) pairs have lines -- everywhere (given) or here -- and, from that, every
+    // line's predecessor barcode in its bundle
+    const uint32_t nb = present_global ? n_bundles : s->n_epochs;
+    if (nb < s->n_epochs) {
+        cleanup();
+        return tec_fail(ctx, TEC_EINVAL, "tec_sc_part23_global: the presence table has fewer bundles than this GPU");
     }
+    const size_t pcells = (size_t)nb * s->n_wl;
+    if ((uint64_t)nb * (s->n_wl + 1ull) >= 0xFFFFFFFFull) {
+        cleanup();
+        return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_part23: bundles x whitelist beyond 2^32");
+    }
+    SC_TRY(present.reserve(pcells));
+    SC_TRY(pred.reserve(pcells));
+    if (present_global) {
+        std::vector<uint32_t> h(pcells);
+        for (size_t i = 0; i < pcells; ++i) h[i] = present_global[i] ? 1u : 0u;
+        SC_TRY(hipMemcpy(present.p, h.data(), pcells * 4, hipMemcpyHostToDevice));
+    } else {
+        SC_TRY(hipMemsetAsync(present.p, 0, pcells * 4, st));
+        hipLaunchKernelGGL(presence_kernel, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
+                           s->n_wl, present.p);
+    }
+    hipLaunchKernelGGL(presence_mark_kernel, dim3(grid_for(pcells)), dim3(kB), 0, st, (uint64_t)pcells, present.p, s->n_wl, pred.p);
+    SC_RC(scan_u32(ctx, s, pred.p, pred.p, pcells, true, rocprim::maximum<uint32_t>()));
     // ---- drop rule, first kept line of a key across bundles
     SC_TRY(kept_rec.reserve(N));
     SC_TRY(firstkept.reserve((size_t)s->n_groups + 1));
@@ -993,7 +1366,7 @@ extern "C" int tec_sc_part23(tec_ctx* ctx, uint32_t n_selected, const uint32_t* 
     SC_TRY(hipMemsetAsync(firstkept.p, 0xFF, ((size_t)s->n_groups + 1) * 4, st));
     SC_TRY(hipMemsetAsync(scal.p, 0, 4 * 8, st));
     hipLaunchKernelGGL(kept_kernel, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
-                       sel.p, selprefix.p, s->gid.p, kept_rec.p, firstkept.p, scal.p);
+                       sel.p, selprefix.p, s->gid.p, pred.p, s->n_wl, kept_rec.p, firstkept.p, scal.p);
     // ---- part 3 queries
     SC_TRY(qflag.reserve(N));
     SC_TRY(qscan.reserve(N));

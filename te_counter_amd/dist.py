@@ -145,3 +145,101 @@ def plan_pairs(reports, rank):
                 extra = rep['first_rec']
                 break
     return skip, extra, (before + skip) // 2
+
+
+# ---- collectives on numpy data (single cell across GPUs: te_counter_amd/scdist.py) --------------------
+
+def _as_tensor(world, a):
+    import torch
+    a = np.ascontiguousarray(a)
+    view = {np.dtype('uint64'): np.int64, np.dtype('uint32'): np.int32, np.dtype('uint16'): np.int16}.get(a.dtype)
+    t = torch.from_numpy(a.view(view) if view else a)
+    return t.to(world._device())
+
+
+def _as_array(t, dtype):
+    a = t.cpu().numpy()
+    return a.view(dtype) if a.dtype != dtype else a
+
+
+def world_sum(world, value):
+    """Sum of one integer over the ranks."""
+    if hasattr(world, 'sum_int'):
+        return world.sum_int(value)
+    if world.size == 1:
+        return int(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int64, device=world._device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def world_max_u8(world, a):
+    """Element-wise max (= OR for 0/1 tables) of a uint8 array over the ranks."""
+    if hasattr(world, 'max_u8'):
+        return world.max_u8(a)
+    if world.size == 1:
+        return a
+    import torch.distributed as dist
+    t = _as_tensor(world, a)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return _as_array(t, np.dtype('uint8'))
+
+
+def all_gather_array(world, a):
+    """Every rank's 1-D array (lengths may differ), in rank order."""
+    if hasattr(world, 'gather_array'):
+        return world.gather_array(a)
+    if world.size == 1:
+        return [a]
+    import torch
+    import torch.distributed as dist
+    sizes = world.gather(int(len(a)))
+    cap = max(1, max(sizes))
+    pad = np.zeros(cap, a.dtype)
+    pad[:len(a)] = a
+    t = _as_tensor(world, pad)
+    outs = [torch.empty_like(t) for _ in range(world.size)]
+    dist.all_gather(outs, t)
+    return [_as_array(o, a.dtype)[:n].copy() for o, n in zip(outs, sizes)]
+
+
+def exchange_rows(world, parts):
+    """All-to-all of row sets: parts[d] = {column: array} destined for rank d (same columns and dtypes on
+    every rank).  Returns the columns received from all ranks, concatenated in source-rank order.
+    Point-to-point sends underneath (RCCL over xGMI, or gloo): every pair of GPUs exchanges exactly its
+    rows once."""
+    if hasattr(world, 'exchange'):
+        return world.exchange(parts)
+    if world.size == 1:
+        return parts[0]
+    import torch
+    import torch.distributed as dist
+    cols = list(parts[0].keys())
+    sizes = world.gather([int(len(p[cols[0]])) for p in parts])  # sizes[src][dst]
+    out = {}
+    for c in cols:
+        dtype = parts[0][c].dtype
+        recv = [None] * world.size
+        ops, keep = [], []
+        for peer in range(world.size):
+            n_in = sizes[peer][world.rank]
+            if peer == world.rank:
+                recv[peer] = np.ascontiguousarray(parts[peer][c])
+                continue
+            if sizes[world.rank][peer]:
+                t = _as_tensor(world, parts[peer][c])
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, peer))
+            if n_in:
+                r = torch.empty(n_in, dtype=_as_tensor(world, np.zeros(1, dtype)).dtype, device=world._device())
+                recv[peer] = r
+                ops.append(dist.P2POp(dist.irecv, r, peer))
+            else:
+                recv[peer] = np.zeros(0, dtype)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        out[c] = np.concatenate([x if isinstance(x, np.ndarray) else _as_array(x, dtype) for x in recv])
+    return out

@@ -130,6 +130,7 @@ class Engine:
         csk = np.ascontiguousarray(class_skip, np.uint8)
         self._check(self._lib.tec_sc_begin(self._ctx, int(bool(stranded)), int(mapq_min), wl.shape[0], _ptr(wl),
                                            int(bundle_keys), len(cic), _ptr(cic), _ptr(csk)))
+        self._n_wl = int(wl.shape[0])
 
     def sc_submit(self, cls, pos, end, flag, mapq, cb24, ub24, tagflags):
         a = (np.ascontiguousarray(cls, np.int32), np.ascontiguousarray(pos, np.int32), np.ascontiguousarray(end, np.int32),
@@ -157,11 +158,75 @@ class Engine:
         self._check(self._lib.tec_sc_part1_fetch(self._ctx, _ptr(ids), _ptr(cnt), _ptr(first)))
         return ids, cnt, first
 
-    def sc_part23(self, selected_ids):
-        """-> dict(kept_lines, cells, cell_hits, coo_cell, coo_name, coo_count)."""
+    # ---- part 1 in steps and the multi-GPU hooks (include/tecount.h; orchestrated by scdist.run_parts)
+    _SURVIVOR_COLUMNS = (('bcid', np.uint32), ('u0', np.uint64), ('u1', np.uint64), ('u2', np.uint64), ('rec', np.uint64),
+                         ('klass', np.int32), ('left', np.int32), ('rite', np.int32))
+
+    def sc_set_record_base(self, base, total_records):
+        self._check(self._lib.tec_sc_set_record_base(self._ctx, int(base), int(total_records)))
+
+    def sc_survivors(self):
+        n = C.c_uint64()
+        self._check(self._lib.tec_sc_survivors(self._ctx, C.byref(n)))
+        rows = {k: np.zeros(n.value, dt) for k, dt in self._SURVIVOR_COLUMNS}
+        self._check(self._lib.tec_sc_survivors_fetch(self._ctx, *[_ptr(rows[k]) for k, _ in self._SURVIVOR_COLUMNS]))
+        return rows
+
+    def sc_survivors_replace(self, rows):
+        cols = [np.ascontiguousarray(rows[k], dt) for k, dt in self._SURVIVOR_COLUMNS]
+        self._check(self._lib.tec_sc_survivors_replace(self._ctx, len(cols[0]), *[_ptr(c) for c in cols]))
+
+    def sc_part1_sort(self):
+        n = C.c_uint64()
+        self._check(self._lib.tec_sc_part1_sort(self._ctx, C.byref(n)))
+        return int(n.value)
+
+    def sc_missing_tags(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.tec_sc_missing_tags(self._ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def sc_epoch_marks(self, lower):
+        n = C.c_uint64()
+        self._check(self._lib.tec_sc_epoch_marks(self._ctx, int(lower), C.byref(n)))
+        return int(n.value)
+
+    def sc_epoch_rank(self, v):
+        n = C.c_uint64()
+        self._check(self._lib.tec_sc_epoch_rank(self._ctx, int(v), C.byref(n)))
+        return int(n.value)
+
+    def sc_epoch_kth(self, k):
+        v = C.c_uint64()
+        self._check(self._lib.tec_sc_epoch_kth(self._ctx, int(k), C.byref(v)))
+        return int(v.value)
+
+    def sc_part1_finish(self, bounds):
+        b = np.ascontiguousarray(bounds, np.uint64)
+        n = C.c_uint64()
+        self._check(self._lib.tec_sc_part1_finish(self._ctx, len(b), _ptr(b) if len(b) else None, C.byref(n)))
+        ids = np.zeros(n.value, np.uint32)
+        cnt = np.zeros(n.value, np.uint64)
+        first = np.zeros(n.value, np.uint64)
+        self._check(self._lib.tec_sc_part1_fetch(self._ctx, _ptr(ids), _ptr(cnt), _ptr(first)))
+        return ids, cnt, first
+
+    def sc_presence(self, n_bundles):
+        out = np.zeros(int(n_bundles) * self._n_wl, np.uint8)
+        self._check(self._lib.tec_sc_presence(self._ctx, int(n_bundles), _ptr(out)))
+        return out
+
+    def sc_part23(self, selected_ids, n_bundles=None, presence=None):
+        """-> dict(kept_lines, cells, cell_hits, coo_cell, coo_name, coo_count).  presence: the OR of all
+        GPUs' (bundle, barcode) tables (multi-GPU), None: this GPU's own."""
         sel = np.ascontiguousarray(selected_ids, np.uint32)
         kept, nc, nz = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        rc = self._lib.tec_sc_part23(self._ctx, len(sel), _ptr(sel), C.byref(kept), C.byref(nc), C.byref(nz))
+        if presence is None:
+            rc = self._lib.tec_sc_part23(self._ctx, len(sel), _ptr(sel), C.byref(kept), C.byref(nc), C.byref(nz))
+        else:
+            pres = np.ascontiguousarray(presence, np.uint8)
+            rc = self._lib.tec_sc_part23_global(self._ctx, len(sel), _ptr(sel), int(n_bundles), _ptr(pres), C.byref(kept),
+                                                C.byref(nc), C.byref(nz))
         if rc == _lib.TEC_ENOSTRAND:
             raise KeyError('strand')
         self._check(rc)

@@ -258,21 +258,20 @@ class measureTE:
         q_int = int(q) if isinstance(q, (int, np.integer)) else None
         log.info('Part 1: Collapsing UMI/CB combinations')
         self.load_genome()  # the reference loads it in part 3 (te_count.py:581); same index either way
-        eng = self._engine
-        if self.world.size > 1 and self.world.rank != 0:
-            # (the single-cell path still runs on one GPU: the other ranks of a multi-GPU launch stand by)
-            self.total_reads = 0
-            return ScResult(self.all_feature_names, whitelist, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint64))
+        eng, world = self._engine, self.world
+        from . import dist as _dist
+        from . import scdist
+        from .bam import byte_range
+        from .gbam import GpuBam, is_bgzf
         # --noumi and a non-int -q end in the reference's crashes: they take the host decoder, which
         # looks at every batch on the way
         on_gpu = self._decoder_for(filename) == 'gpu' and UMIS and q_int is not None
-        n_records = 0
-        if on_gpu:
-            from .gbam import GpuBam
-            src = GpuBam(eng, filename)
-        else:
-            src = self._open(filename)
+        ranged = world.size > 1 and not hasattr(filename, 'batches') and is_bgzf(filename)
+        rng = byte_range(os.path.getsize(filename), world.rank, world.size) if ranged else None
+        n_records, failure, report = 0, None, None
+        src = None
         try:
+            src = GpuBam(eng, filename, rng) if on_gpu else self._open(filename, rng)
             skip, cls_of_tid, keys = _reads.chrom_class_table(src.reference_names)
             key_skip = np.zeros(len(keys), np.uint8)
             for t, c in enumerate(cls_of_tid):
@@ -280,11 +279,13 @@ class measureTE:
             key_chrom = np.array([self.genome._chrom_lookup.get(k, -1) for k in keys], np.int32)
             eng.sc_begin(strand, q_int or 0, _reads.pack_whitelist(whitelist), self.BUNDLE_KEYS, key_chrom, key_skip)
             if on_gpu:
-                rep = src.run_sc(q_int, cls_of_tid)
-                self.decode_report = rep
-                n_records = rep['n_records']
+                report = src.run_sc(q_int, cls_of_tid)
+                self.decode_report = report
+                n_records = report['n_records']
             else:
-                for batch in src.batches(want_tags=True):
+                for ordinal, batch in enumerate(src.batches(want_tags=True)):
+                    if world.size > 1 and not ranged and not world.mine(0):
+                        continue  # a source that cannot be cut into ranges is read by rank 0 alone
                     n_records += len(batch)
                     if q_int is None and self._reaches_mapq_test(batch, False):
                         raise TypeError("'<' not supported between instances of 'int' and '%s'" % type(q).__name__)
@@ -294,23 +295,31 @@ class measureTE:
                         # (te_count.py:428-442); only the CB|CR assertion can still fire
                         arrays = arrays[:7] + (arrays[7] | 2,)
                     eng.sc_submit(*arrays)
-            ids, counts, first = eng.sc_part1()
+                if ranged:
+                    first, end, has = src.range_tokens()
+                    report = {'n_records': n_records, 'has_records': has and n_records > 0, 'first_token': first, 'end_token': end}
+        except Exception as e:  # noqa: BLE001 -- the other ranks must hear about it before the next collective
+            if world.size == 1:
+                raise
+            failure = e
         finally:
-            src.close()
-        self.total_reads = n_records + 1  # te_count.py:373,705
+            if src is not None:
+                src.close()
+        world.raise_together(failure)
+        if ranged:
+            _dist.check_ranges(world.gather({k: report[k] for k in ('n_records', 'has_records', 'first_token', 'end_token')}),
+                               os.path.getsize(filename))
         if not UMIS:
+            eng.sc_part1()  # (the CB|CR assertion)
             eng.sc_end()
+            self.total_reads = _dist.world_sum(world, n_records) + 1
             raise ZeroDivisionError('division by zero')  # te_count.py:703: no UMI was ever stored
-
-        # ---- part 2 selection (te_count.py:502): best maxcells+1000 raw counts, ties first-seen first
         log.info(f'Part 2: Get the best {maxcells} barcodes and remove dupes')
-        log.info(f'  Observed {len(ids):,} raw barcodes')
-        order = np.lexsort((first, -counts.astype(np.int64)))
-        selected = np.sort(ids[order[0:maxcells + self.CELL_PAD]])
-        out = eng.sc_part23(selected)
-        st = eng.sc_stats()
-        eng.sc_end()
+        out = scdist.run_parts(eng, world, n_records, self.BUNDLE_KEYS, maxcells, self.CELL_PAD)
+        self.total_reads = out['total_records'] + 1  # te_count.py:373,705
+        st = out['stats']
         self.stats = st
+        log.info(f"  Observed {len(out['raw_ids']):,} raw barcodes")
         log.info(f"  Preserved {out['kept_lines']:,}/{self.total_reads:,} "
                  f"({out['kept_lines'] / self.total_reads * 100:.1f}%) of the reads")
         log.info('Part 3: Mapping the remaining UMIs to features')

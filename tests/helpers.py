@@ -22,3 +22,57 @@ def units_from_records(flat, records, paired, q=20, batch_size=1 << 20):
 
 def flat_from_golden(g):
     return FlatIndex.from_features(g['features'])
+
+
+class ThreadWorld:
+    """Test double of te_counter_amd.dist.World for N ranks that are THREADS of one process (e.g. N engine
+    contexts on one GPU): the collectives scdist / measure use, over a shared mailbox and a barrier."""
+
+    class Shared:
+        def __init__(self, size):
+            import threading
+            self.size = size
+            self.barrier = threading.Barrier(size)
+            self.box = [None] * size
+
+    def __init__(self, rank, shared):
+        self.rank, self.size, self.local_rank, self.backend = rank, shared.size, 0, 'threads'
+        self._s = shared
+
+    def gather(self, obj):
+        self._s.box[self.rank] = obj
+        self._s.barrier.wait()
+        out = list(self._s.box)
+        self._s.barrier.wait()
+        return out
+
+    def raise_together(self, exc):
+        for r in self.gather(None if exc is None else exc):
+            if r is not None:
+                raise r
+
+    def sum_int(self, v):
+        return sum(self.gather(int(v)))
+
+    def max_u8(self, a):
+        import numpy as np
+        return np.maximum.reduce(self.gather(a))
+
+    def gather_array(self, a):
+        return self.gather(a)
+
+    def exchange(self, parts):
+        import numpy as np
+        allparts = self.gather(parts)
+        return {c: np.concatenate([allparts[src][self.rank][c] for src in range(self.size)]) for c in parts[0]}
+
+    def mine(self, ordinal):
+        return ordinal % self.size == self.rank
+
+    def sum_counts(self, counts, stats_vec):
+        import numpy as np
+        got = self.gather((counts, np.asarray(stats_vec, np.int64)))
+        return np.sum([g[0] for g in got], axis=0).astype(np.uint64), np.sum([g[1] for g in got], axis=0)
+
+    def close(self):
+        pass

@@ -67,3 +67,53 @@ def test_random_vs_oracle(seed, strand, thr, tmp_path):
     assert list(m.barcodes.items()) == list(want_bc.items())
     assert res == want_res
     assert (tsv, freq) == orc.format_sc_tsv(want_res, want_bc, 25)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('name', ['sc_rand21_strand_multibundle', 'sc_rand22_nostrand_multibundle', 'sc_topcells_binding_multibundle',
+                                  'sc_rand22_strand', 'sc_degenerate_boundary'])
+def test_cells_dealt_over_several_gpu_contexts(name, world, tmp_path):
+    """The multi-GPU single-cell decomposition with the REAL kernels: N engine contexts on this GPU, one per
+    rank (threads), each decoding its own byte range of one BAM file on the device; survivors exchanged by
+    barcode id, bundle boundaries by distributed bisection, global selection and presence tables -- merged
+    result, barcode order, TSV and barcode_freq equal the reference's goldens."""
+    import threading
+    from helpers import ThreadWorld
+    from te_counter_amd import bam
+    g = load_golden(name)
+    p = g['params']
+    flat = flat_from_golden(g)
+    wlf = tmp_path / 'wl.txt'
+    wlf.write_text(''.join(b + '\n' for b in g['whitelist']))
+    path = str(tmp_path / 'in.bam')
+    bam.write_bam(path, ListSource(g['records']).reference_names, g['records'], block_bytes=2500)
+    shared = ThreadWorld.Shared(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            m = measureTE('t', p['q'], world=ThreadWorld(r, shared))
+            m.BUNDLE_KEYS = p['bundle_threshold']
+            m.bind_genome(flat)
+            res = m.sc_parse_bamse(path, whitelistfilename=str(wlf), strand=p['strand'], label='lab', maxcells=p['maxcells'])
+            if r == 0:
+                o = str(tmp_path / 'o.tsv')
+                m.sc_save_result(res, o, maxcells=p['maxcells'])
+                out[0] = (m, res, open(o).read(), open(o.replace('.tsv', '.barcode_freq.tsv')).read())
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    m, res, tsv, freq = out[0]
+    assert m.total_reads == g['expected']['total_reads']
+    assert [list(kv) for kv in m.barcodes.items()] == g['expected']['barcodes']
+    assert res == g['expected']['result']
+    assert tsv == g['expected']['tsv'] and freq == g['expected']['barcode_freq']
+    if 'multibundle' in name:
+        assert m.stats['bundles'] > 1
