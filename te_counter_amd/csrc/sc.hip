@@ -918,6 +918,7 @@ int sc_epoch_marks(tec_ctx* ctx, tec_sc_state* s, long long lower, uint64_t* n_m
     SC_HIP(rocprim::radix_sort_keys(nullptr, bytes, s->k64a.p, s->marks.p, m, 0, bits_for(s->max_rec + 1), st));
     SC_HIP(s->tmp.reserve(bytes));
     SC_HIP(rocprim::radix_sort_keys(s->tmp.p, bytes, s->k64a.p, s->marks.p, m, 0, bits_for(s->max_rec + 1), st));
+    SC_HIP(hipStreamSynchronize(st));  // callers read marks with plain hipMemcpy, which does not wait for this (non-blocking) stream
     return TEC_OK;
 }
 
@@ -1254,7 +1255,8 @@ extern "C" int tec_sc_presence(tec_ctx* ctx, uint32_t n_bundles, uint8_t* presen
         hipLaunchKernelGGL(presence_kernel, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
                            s->n_wl, pres.p);
         std::vector<uint32_t> h(cells);
-        e = hipMemcpy(h.data(), pres.p, cells * 4, hipMemcpyDeviceToHost);
+        e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(h.data(), pres.p, cells * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess)
             for (size_t i = 0; i < cells; ++i) present[i] = h[i] ? 1 : 0;
     }

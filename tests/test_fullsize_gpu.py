@@ -132,7 +132,8 @@ def test_config4_full_size_single_cell():
     assert st['qcfail'] + st['lowq'] + st['invalid_barcode'] + st['skipped_chrom'] + st['survivors'] == n
     # a (CB,UB) key has at most one bundle line per spill epoch; the reader keeps a subset of the lines
     assert st['keys'] <= st['survivors'] and st['kept_lines'] <= st['keys'] * st['bundles']
-    assert len(ids) == 10000 and int(counts.sum()) >= st['keys']
+    # (a mutated off-whitelist barcode lands on another whitelist entry now and then: a few more than 10 000 cells)
+    assert 10000 <= len(ids) <= 10100 and int(counts.sum()) >= st['keys']
     # per-cell totals: the COO triplets of a cell sum to at least its number of assigned UMIs
     assert len(out['cells']) <= 10000 and int(out['coo_count'].sum()) >= st['assigned'] > 0
     assert np.all(np.diff(out['coo_cell'].astype(np.int64) * (1 << 32) + out['coo_name']) > 0)  # sorted, unique
