@@ -478,6 +478,7 @@ def secondary(ann, eng, args):
         dt = time.perf_counter() - t
         kernel_ms, launches = eng.bulk_kernel_time()
         reduce_ms, launch_ms = eng.bulk_reduce_time(), eng.bulk_launch_times()
+        spill_ms, spill_names = eng.bulk_spill_time()
         single, _ = run.count(1)
         if not np.array_equal(counts, single * 5):
             raise SystemExit('PARITY FAILURE: linearity violated in ' + key)
@@ -485,6 +486,9 @@ def secondary(ann, eng, args):
                     'names': a.flat.n_names, 'assigned_frac': round(st['assigned'] / 5 / run.n_units, 4),
                     'roofline': run.roofline(kernel_ms, launches, reduce_ms, launch_ms,
                                              traffic_for(None, genome, layout, order, run.n_units))}
+        if spill_names:  # names beyond the LDS histogram: sorted + run-length encoded after each launch
+            out[key]['spill_fold_ms_per_launch'] = round(spill_ms / max(1, launches), 3)
+            out[key]['spilled_names_per_launch'] = int(spill_names // max(1, launches))
         run.release()
     return out
 

@@ -157,6 +157,10 @@ int tec_bulk_kernel_time(tec_ctx* ctx, double* total_ms, uint64_t* launches);
  * tec_bulk_begin; the first min(capacity, *n) of them are written to ms (may be NULL). */
 int tec_bulk_launch_times(tec_ctx* ctx, float* ms, uint64_t capacity, uint64_t* n);
 
+/* With more names than the per-workgroup LDS histogram holds (77 k), hits on the remaining names are appended to a
+ * list that is sorted and run-length encoded after every launch: its GPU time (ms) and length since tec_bulk_begin. */
+int tec_bulk_spill_time(tec_ctx* ctx, double* total_ms, uint64_t* names);
+
 /* Duration (ms) of the small kernels that fold the per-workgroup histogram rows into the count
  * vector after each count kernel, since tec_bulk_begin. */
 int tec_bulk_reduce_time(tec_ctx* ctx, double* total_ms);

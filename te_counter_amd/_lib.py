@@ -56,6 +56,7 @@ _SIGNATURES = {
     'tec_bulk_finish': (C.c_int, [_p, _p, C.POINTER(Stats)]),
     'tec_bulk_kernel_time': (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     'tec_bulk_launch_times': (C.c_int, [_p, _p, _u64, C.POINTER(_u64)]),
+    'tec_bulk_spill_time': (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     'tec_bulk_reduce_time': (C.c_int, [_p, C.POINTER(C.c_double)]),
     'tec_sc_begin': (C.c_int, [_p, C.c_int, C.c_int, C.c_uint32, _p, _u64, C.c_uint32, _p, _p]),
     'tec_sc_submit': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),

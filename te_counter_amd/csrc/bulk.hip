@@ -169,8 +169,27 @@ struct FastSink {
     uint32_t* lds;
     uint32_t k_lds;
     unsigned long long* counts;
+    // Names beyond the LDS histogram (an annotation with millions of names: BASELINE config 5) are not
+    // counted with one memory-side 64-bit atomic per hit -- 145 M scattered atomics per 100 M-unit launch
+    // ran at 3 % of the HBM roofline -- but appended to a spill list that is already split by BUCKET (the
+    // top bits of the name id): this workgroup's slice of bucket b is spill[(b * n_wg + wg) * cap ...],
+    // filled through cursor b in LDS.  After the launch one workgroup per bucket counts its slices in an
+    // LDS histogram and adds it to the count vector with plain stores (spill.hip): no sort, no atomics
+    // on memory, nothing for the host to wait for.  A full slice falls back to the global atomic.
+    uint32_t* spill;         // nullptr: no spill list
+    uint32_t spill_cap;      // entries per (bucket, workgroup) slice
+    uint32_t spill_lo;       // bucket = name >> spill_lo
+    uint32_t* spill_cursor;  // [n_buckets] in LDS
     __device__ __forceinline__ uint32_t add(uint32_t name) const {
         if (ALL_LDS || name < k_lds) return atomicAdd(&lds[name >> 1], 1u << ((name & 1u) * 16u));
+        if (spill) {
+            const uint32_t b = name >> spill_lo;
+            const uint32_t pos = atomicAdd(&spill_cursor[b], 1u);
+            if (pos < spill_cap) {
+                spill[((size_t)b * gridDim.x + blockIdx.x) * spill_cap + pos] = name;
+                return 0u;
+            }
+        }
         atomicAdd(&counts[name], 1ull);
         return 0u;  // never reads as a carry
     }
@@ -297,7 +316,8 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
                                                            const uint8_t* __restrict__ mapq, uint64_t n, int mapq_min,
                                                            unsigned long long* counts, unsigned long long* stats,
                                                            uint32_t k_lds, uint64_t span, uint32_t flags,
-                                                           uint32_t* slabs) {
+                                                           uint32_t* slabs, uint32_t* spill, uint32_t spill_cap,
+                                                           uint32_t* spill_counts) {
     extern __shared__ uint32_t hist[];
     constexpr uint32_t chunk = U * kBlock;
     const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // whole 16-byte pieces
@@ -552,7 +572,9 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                                                                const uint8_t* __restrict__ mapq, uint64_t n,
                                                                int mapq_min, unsigned long long* counts,
                                                                unsigned long long* stats, uint32_t k_lds, uint64_t span,
-                                                               uint32_t flags, uint32_t* slabs) {
+                                                               uint32_t flags, uint32_t* slabs, uint32_t* spill,
+                                                               uint32_t spill_cap, uint32_t* spill_counts) {
+    // (spill_cap: low 24 bits = entries per slice, high 8 bits = log2 of the names per bucket)
     extern __shared__ uint32_t hist[];
     // per-chromosome {first fine bin, bin count} in LDS: one dependent global gather less per unit
     __shared__ uint2 chrom_tab[kChromLds];
@@ -565,7 +587,14 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};  // exact path only
-    const FastSink<ALL_LDS> fast{hist, k_lds, counts};
+    // bucket cursors of the spill list sit behind the histogram in dynamic LDS
+    const uint32_t spill_lo = spill_cap >> 24, slice_cap = spill_cap & 0xFFFFFFu;
+    const uint32_t n_buckets = (!ALL_LDS && spill) ? ((idx.n_names + (1u << spill_lo) - 1u) >> spill_lo) : 0u;
+    uint32_t* const cursors = hist + words;
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += kBlock) cursors[b] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const FastSink<ALL_LDS> fast{hist, k_lds, counts, (!ALL_LDS && spill) ? spill : nullptr, slice_cap, spill_lo, cursors};
 #ifdef TEC_DIAGNOSTICS
     const bool mute = (flags & 2u) != 0;  // TEC_ABLATE
     unsigned sinkhole = 0;                // keeps ablated loads alive
@@ -826,6 +855,8 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
         TEC_CLK(3);  // tests + counting
     }
     store_hist(hist, words, slabs + (size_t)blockIdx.x * words);
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += kBlock)  // (store_hist ended with a barrier: every append is done)
+        spill_counts[(size_t)b * gridDim.x + blockIdx.x] = cursors[b] < slice_cap ? cursors[b] : slice_cap;
     TEC_CLK(5);  // final flush
     TEC_CLK_STORE;
 #ifdef TEC_DIAGNOSTICS
@@ -1051,7 +1082,7 @@ __global__ __launch_bounds__(kBlock) void part_scan_kernel(const uint32_t* wsize
 
 typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
                                const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t,
-                               uint64_t, uint32_t, uint32_t*);
+                               uint64_t, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*);
 
 template <int U>
 count_kernel_t pick_rec(bool mixed, bool all_lds) {
@@ -1114,7 +1145,7 @@ int harvest_timers(tec_ctx* ctx) {
         ctx->reduce_ms += ms;
     }
     ctx->red_used = 0;
-    return TEC_OK;
+    return tec_spill_harvest(ctx);
 }
 
 // Folds the histogram rows of the launches since the last reduce into the count vector.
@@ -1170,9 +1201,17 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     // to global atomics.  One 1024-thread workgroup per CU: the kernels are compiled for four
     // waves per SIMD (~100 VGPRs), so a second workgroup would not be co-resident anyway.
     uint32_t budget = ctx->lds_bytes ? ctx->lds_bytes : kLdsMaxBytes;
+    // names that do not fit go to a bucketed spill list (FastSink): its bucket cursors live behind the histogram
+    unsigned name_bits = 1;
+    while (name_bits < 32 && (ctx->idx.n_names >> name_bits)) ++name_bits;
+    const uint32_t spill_lo = name_bits > 8 ? std::min(name_bits - 8, 14u) : 0u;
+    const uint32_t n_buckets = (ctx->idx.n_names + (1u << spill_lo) - 1u) >> spill_lo;
+    const bool may_spill = ctx->idx.n_names > budget / 2 && ctx->spill_enabled && n_buckets <= 1024 && ctx->kernel_variant == 2 &&
+                           ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3 && !ctx->partition;
+    if (may_spill) budget -= (n_buckets * 4u + 15u) & ~15u;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, budget / 2);
     const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // as the kernels compute it
-    const size_t lds = (size_t)words * 4;
+    const size_t lds = (size_t)words * 4 + (may_spill ? (size_t)n_buckets * 4 : 0);
     const unsigned grid = (unsigned)std::min<uint64_t>(want, (uint64_t)ctx->n_cu);
     // one histogram row per workgroup; reduce_slabs_kernel folds them into the count vector
     if (ctx->slab_slot && ctx->slab_words != words) {  // the histogram width changed: fold what is pending first
@@ -1253,17 +1292,33 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
                            ctx->idx, reinterpret_cast<const int32_t*>(items), reinterpret_cast<const int32_t*>(pm),
                            (const int32_t*)nullptr, (const uint16_t*)nullptr, (const uint8_t*)nullptr, (uint64_t)0,
                            ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, (uint64_t)1, (uint32_t)ctx->aggregate,
-                           slab);
+                           slab, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
         TEC_HIP(ctx, hipGetLastError());
         TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
     } else {
         // start / stop timestamps ride on the dispatch itself: no barrier packets between the launches
+        // names beyond the LDS histogram go to a bucketed spill list (see FastSink), folded right after the launch
+        const bool spilling = may_spill && rec_ok && k_lds < ctx->idx.n_names;
+        uint32_t spill_cap = 0;
+        if (spilling) {
+            // room for three names per unit, spread over the buckets (a unit adds at most six on the fast path,
+            // config 5 averages 1.45); a slice that fills up falls back to global atomics
+            const uint64_t per_wg = (n + grid - 1) / grid;
+            spill_cap = (uint32_t)std::min<uint64_t>((per_wg * 3 + n_buckets - 1) / n_buckets + 64, 0xFFFFFFull);
+            int rc = tec_spill_reserve(ctx, grid, n_buckets, spill_cap);
+            if (rc) return rc;
+        }
         hipExtLaunchKernelGGL(pick_kernel(mixed, unroll, rec_ok ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid),
                               dim3(kBlock), (uint32_t)lds, ctx->s_compute, timed ? ev.start : (hipEvent_t) nullptr,
                               timed ? ev.stop : (hipEvent_t) nullptr, 0u, ctx->idx, u.chrom, u.p1, u.p2,
                               u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                              (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, slab);
+                              (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
+                              spill_cap | (spill_lo << 24), ctx->d_spill_counts);
         TEC_HIP(ctx, hipGetLastError());
+        if (spilling) {
+            int rc = tec_spill_fold(ctx, grid, n_buckets, spill_lo, spill_cap);
+            if (rc) return rc;
+        }
     }
     // the rows wait in their slot; one reduce folds kSlabSlots launches (or what is pending at the next sync)
     ctx->slab_used[ctx->slab_slot++] = rows;
@@ -1315,6 +1370,8 @@ int tec_bulk_init(tec_ctx* ctx) {
     ctx->partition = e ? atoi(e) : 0;  // 2: also for tiny batches (tests)
     e = getenv("TEC_PART_WSHIFT");  // tuning knob: log2(fine bins per window), 0 = automatic
     ctx->part_wshift = e ? atoi(e) : 0;
+    e = getenv("TEC_SPILL");  // 0: names beyond the LDS histogram are counted with global atomics (the round-1 path)
+    ctx->spill_enabled = !(e && atoi(e) == 0);
     e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
     ctx->span_div = e && atoi(e) > 0 ? atoi(e) : 8;
     return TEC_OK;
@@ -1366,6 +1423,8 @@ extern "C" int tec_bulk_begin(tec_ctx* ctx, int mapq_min) {
     ctx->kernel_launches = 0;
     ctx->timed_launches = 0;
     ctx->launch_ms.clear();
+    ctx->spill_ms = 0.0;
+    ctx->spill_names = 0;
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)ctx->idx.n_names + 2) * sizeof(unsigned long long), ctx->s_compute));
     TEC_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), ctx->s_compute));
     ctx->bulk_open = true;
@@ -1515,6 +1574,15 @@ extern "C" int tec_bulk_launch_times(tec_ctx* ctx, float* ms, uint64_t capacity,
     *n = ctx->launch_ms.size();
     if (ms)
         for (uint64_t i = 0; i < capacity && i < *n; ++i) ms[i] = ctx->launch_ms[i];
+    return TEC_OK;
+}
+
+extern "C" int tec_bulk_spill_time(tec_ctx* ctx, double* total_ms, uint64_t* names) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_spill_time: NULL context");
+    int rc = tec_bulk_sync(ctx);
+    if (rc) return rc;
+    if (total_ms) *total_ms = ctx->spill_ms;
+    if (names) *names = ctx->spill_names;
     return TEC_OK;
 }
 

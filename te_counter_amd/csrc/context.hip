@@ -60,6 +60,7 @@ extern "C" void tec_destroy(tec_ctx* ctx) {
     tec_bulk_release(ctx);
     tec_sc_release(ctx);
     tec_gbam_cache_release(ctx);
+    tec_spill_release(ctx);
     if (ctx->d_int2ext) (void)hipFree(ctx->d_int2ext);
     if (ctx->d_index_blob) (void)hipFree(ctx->d_index_blob);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);

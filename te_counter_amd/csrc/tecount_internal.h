@@ -104,6 +104,15 @@ struct tec_ctx {
     int ablate = 0;  // diagnostics (TEC_ABLATE)
     uint32_t lds_bytes = 0;  // 0 = automatic
     int span_div = 8;
+    // spill list of hit names beyond the LDS histogram (bulk.hip FastSink, spill.hip)
+    bool spill_enabled = true;
+    uint32_t *d_spill = nullptr, *d_spill_counts = nullptr;
+    unsigned long long* d_spill_total = nullptr;
+    size_t spill_cap_total = 0, spill_counts_cap = 0;
+    std::vector<tec_event_pair> spill_ev;  // start / stop of the fold kernels
+    size_t spill_ev_used = 0;
+    double spill_ms = 0.0;
+    uint64_t spill_names = 0;
 };
 
 int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
@@ -119,6 +128,11 @@ int tec_fail(tec_ctx* ctx, int code, const char* fmt, ...);
 // bulk.hip
 int tec_bulk_init(tec_ctx* ctx);
 int tec_bulk_release(tec_ctx* ctx);
+// spill.hip
+int tec_spill_reserve(tec_ctx* ctx, uint32_t n_wg, uint32_t n_buckets, uint32_t slice_cap);
+int tec_spill_fold(tec_ctx* ctx, uint32_t n_wg, uint32_t n_buckets, uint32_t lo, uint32_t slice_cap);
+int tec_spill_harvest(tec_ctx* ctx);
+void tec_spill_release(tec_ctx* ctx);
 // sc.hip
 void tec_sc_release(tec_ctx* ctx);
 // gbam.hip

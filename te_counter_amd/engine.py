@@ -118,6 +118,11 @@ class Engine:
             self._check(self._lib.tec_bulk_launch_times(self._ctx, _ptr(out), n.value, C.byref(n)))
         return out
 
+    def bulk_spill_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._lib.tec_bulk_spill_time(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def bulk_reduce_time(self):
         ms = C.c_double()
         self._check(self._lib.tec_bulk_reduce_time(self._ctx, C.byref(ms)))
