@@ -27,6 +27,7 @@ PY
 for p in random illumina; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gbam_$p/trace -o x -- python3 /tmp/run_one.py /tmp/prof_$p.bam > gpurun_out/prof_gbam_$p.log 2>&1
   grep decode_and_count gpurun_out/prof_gbam_$p.log
+  [ -n "$TRACE_ONLY" ] && continue
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/prof_gbam_$p/pmc1 -o x -- python3 /tmp/run_one.py /tmp/prof_$p.bam > gpurun_out/prof_gbam_${p}_pmc1.log 2>&1
   rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_IFETCH --output-format csv -d gpurun_out/prof_gbam_$p/pmc2 -o x -- python3 /tmp/run_one.py /tmp/prof_$p.bam > gpurun_out/prof_gbam_${p}_pmc2.log 2>&1
 done
