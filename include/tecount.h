@@ -286,8 +286,10 @@ int tec_bam_range_tokens(tec_bam* r, uint64_t first[2], uint64_t end[2], int* ha
 uint64_t tec_bam_file_size(const tec_bam* r);
 void tec_bam_close(tec_bam* r);
 /* Raw DEFLATE (RFC 1951) of one BGZF block body into exactly out_len bytes: the decoder the BAM
- * reader uses in place of pysam / htslib (te_count.py:65, 190, 351); use_zlib != 0 runs zlib's
- * inflate instead (the referee in tests).  TEC_OK, or TEC_EINVAL for a malformed / short / long stream. */
+ * reader uses in place of pysam / htslib (te_count.py:65, 190, 351); use_zlib == 1 runs zlib's
+ * inflate instead (the referee in tests), use_zlib == 2 the host build of the decoder one GPU lane
+ * runs in the on-GPU front end (csrc/ginflate.h -- the same source, so the CPU suite pins it against
+ * zlib).  TEC_OK, or TEC_EINVAL for a malformed / short / long stream. */
 int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_len, int use_zlib);
 
 const char* tec_bam_last_error(const tec_bam* r);

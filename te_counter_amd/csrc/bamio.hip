@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "bamscan.h"
+#include "ginflate.h"
 #include "inflate_fast.h"
 #include "tecount_internal.h"
 
@@ -441,6 +442,14 @@ extern "C" int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out,
         const int rc = inflate(&zs, Z_FINISH);
         inflateEnd(&zs);
         return rc == Z_STREAM_END && zs.avail_out == 0 ? TEC_OK : TEC_EINVAL;
+    }
+    if (use_zlib == 2) {  // the GPU lane decoder (ginflate.h), host instantiation of the same source
+        if (in_len > 0x7FFFFFFFull || out_len > 0x7FFFFFFFull) return TEC_EINVAL;
+        std::vector<uint8_t> padded(in_len + tec_ginf::kInPad, 0);  // the decoder reads whole 8-byte words
+        if (in_len) memcpy(padded.data(), in, in_len);
+        std::unique_ptr<tec_ginf::HostMem> m(new tec_ginf::HostMem);
+        memset(m.get(), 0x77, sizeof(tec_ginf::HostMem));
+        return tec_ginf::inflate_stream(padded.data(), (uint32_t)in_len, out, (uint32_t)out_len, *m) == tec_ginf::kOk ? TEC_OK : TEC_EINVAL;
     }
     std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
     return tec_inflate::inflate_block(in, in_len, out, out_len, tabs.get()) ? TEC_OK : TEC_EINVAL;

@@ -19,7 +19,6 @@
 //   reduce_slabs_kernel    folds the per-workgroup histogram rows into the u64 count vector
 //   count_bulk_kernel      the CSR walk (indexes without records: bins wider than 32 kb, more than
 //                          512 chromosomes); also the exact path's walk_hits lives here
-//   part_*_kernel          the experimental partitioned pipeline (TEC_PARTITION, off by default)
 #include <algorithm>
 #include <cstdlib>
 
@@ -33,12 +32,6 @@ constexpr uint32_t kNameMask = (1u << TEC_META_NAME_BITS) - 1;
 constexpr uint32_t kCountable = (1u << TEC_CLASS_GENE) | (1u << TEC_CLASS_TE) | (1u << TEC_CLASS_SNRNA);
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kNoName = 0xFFFFFFFFu;
-// layout of the partition's device-side bookkeeping array (uint32): see the partitioned pipeline below
-#define TEC_PM_TICK 0u
-#define TEC_PM_NCHUNKS 8u
-#define TEC_PM_CBASE 16u
-#define TEC_PM_TOTAL 24u
-#define TEC_PM_CHUNKS 32u
 constexpr int kBlock = 1024;
 #ifndef TEC_REC_WAVES
 #define TEC_REC_WAVES 4  // min waves per SIMD the record kernel is compiled for (one 1024-thread workgroup per CU)
@@ -561,10 +554,7 @@ __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const uint4 c0,
     }
 }
 
-// ITEMS: the partitioned pipeline (below): `chrom` carries the 16-byte items {bin record of p1 |
-// one << 31, bin record of p2, p1, p2} of the live units grouped by genome window, `p1` the
-// partition's chunk lists; filters and chromosome lookups were done by the scatter pass.
-template <bool MIXED, int U, int NE, bool ALL_LDS, bool ITEMS>
+template <bool MIXED, int U, int NE, bool ALL_LDS>
 __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
                                                                const int32_t* __restrict__ p1,
                                                                const int32_t* __restrict__ p2,
@@ -609,87 +599,30 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     // first-launched (oldest, issue-favoured) waves finished ~18 % ahead and then idled at the
     // final barrier while the rest ran on with too few waves left to hide the gather latency.
     constexpr uint32_t piece = U * 64u;
-    const uint32_t per_span = ITEMS ? 1u : (uint32_t)(span / piece);  // span is a whole number of chunks
+    const uint32_t per_span = (uint32_t)(span / piece);  // span is a whole number of chunks
     const uint64_t n_spans = (n + span - 1) / span;
     const uint64_t my_spans = blockIdx.x < n_spans ? (n_spans - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const uint32_t tickets = (uint32_t)(my_spans * per_span);  // the host keeps this below 2^32
     const unsigned lane = threadIdx.x & 63u;
-    // ITEMS: the waves of the workgroups on one XCD draw 2048-item chunks from that XCD's list
-    // (chunks of one genome window are consecutive, so the XCD's L2 holds the window's records)
-    const uint4* __restrict__ items = reinterpret_cast<const uint4*>(chrom);
-    uint32_t* pm = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(p1));
-    const uint32_t xcd = blockIdx.x & 7u;
-    uint32_t c_pos = 0, c_rem = 0;
-    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t c_next = (blockIdx.x >> 3) * (kBlock / 64u) + wave_id;
-    const uint32_t c_step = (gridDim.x >> 3) * (kBlock / 64u);
-    const uint32_t pm_nchunks = ITEMS ? pm[TEC_PM_NCHUNKS + xcd] : 0u, pm_cbase = ITEMS ? pm[TEC_PM_CBASE + xcd] : 0u;
-    const uint32_t binmask = (1u << idx.shift) - 1u;
     for (;;) {
         uint64_t base;
         uint32_t left;  // units of this piece
-        if (ITEMS) {
-            if (c_rem == 0) {
-                // static striping of the XCD's chunk list over its waves: a shared ticket counter
-                // (4096 waves on one line of memory-side atomics, ~100 ns each) serialized the kernel
-                const uint32_t c = c_next;
-                c_next += c_step;
-                if (c >= pm_nchunks) break;
-                const uint2 ch2 = *reinterpret_cast<const uint2*>(&pm[TEC_PM_CHUNKS + 2u * (pm_cbase + c)]);
-                c_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch2.x);
-                c_rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch2.y);
-                if (c_rem == 0) continue;
-            }
-            base = c_pos;
-            left = c_rem < piece ? c_rem : piece;
-            c_pos += left;
-            c_rem -= left;
-        } else {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(&ticket, 1u);
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-            if (t >= tickets) break;
-            const uint32_t sj = t / per_span, sr = t - sj * per_span;
-            base = ((uint64_t)blockIdx.x + (uint64_t)sj * gridDim.x) * span + (uint64_t)sr * piece;
-            if (base >= n) continue;  // the tail of the batch's last span
-            const uint64_t left_u = n - base;
-            left = left_u > (uint64_t)piece ? piece : (uint32_t)left_u;
-        }
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&ticket, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= tickets) break;
+        const uint32_t sj = t / per_span, sr = t - sj * per_span;
+        base = ((uint64_t)blockIdx.x + (uint64_t)sj * gridDim.x) * span + (uint64_t)sr * piece;
+        if (base >= n) continue;  // the tail of the batch's last span
+        const uint64_t left_u = n - base;
+        left = left_u > (uint64_t)piece ? piece : (uint32_t)left_u;
         TEC_CLK(4);  // loop overhead
         Unit un[U];
         bool live[U];
         BinRec<NE> ra[U], rb[U];
         bool one[U];
         int xa1[U], xa2[U], xb2[U];
-        uint32_t iga[U], igb[U];  // ITEMS: global bins of the two edges (for the exact walk)
         int ch[U];
-        if (ITEMS) {
-            const uint4* __restrict__ it_b = items + base;
-            uint4 it[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = (uint32_t)k * 64u + lane;
-                live[k] = i < left;
-                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&it_b[live[k] ? i : 0u]));
-                it[k] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            TEC_CLK(0);
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                one[k] = live[k] && (it[k].x >> 31) != 0;
-                iga[k] = live[k] ? it[k].x & 0x7FFFFFFFu : idx.zero_rec;
-                igb[k] = live[k] ? it[k].y : idx.zero_rec;
-                un[k].p1 = (int)it[k].z;
-                un[k].p2 = (int)it[k].w;
-                ch[k] = 0;
-                ra[k] = load_rec<NE>(idx.recs, iga[k]);
-                rb[k] = load_rec<NE>(idx.recs, igb[k]);
-                xa1[k] = (int)(it[k].z & binmask) + 1;
-                xa2[k] = un[k].p2 - (int)(it[k].z & ~binmask) + 1;
-                xb2[k] = (int)(it[k].w & binmask) + 1;
-            }
-        } else {
         // ---- stage 1: the unit SoA (streamed, non-temporal).  `base` is wave-uniform, so every
         // address is a scalar base plus a 32-bit lane offset (no 64-bit vector address math)
         unsigned fl[U], mq[U];
@@ -745,13 +678,11 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
             const bool va = live[k] && un[k].p1 >= 0 && ba < nb, vb = live[k] && un[k].p2 >= 0 && bb < nb;
             one[k] = va && vb && ba == bb;  // both edges in one bin: its record answers both tests
-            iga[k] = igb[k] = 0;
             ra[k] = load_rec<NE>(idx.recs, va ? cb + ba : idx.zero_rec);
             rb[k] = load_rec<NE>(idx.recs, vb && !one[k] ? cb + bb : idx.zero_rec);
             xa1[k] = un[k].p1 - (int)(ba << idx.shift) + 1;
             xa2[k] = un[k].p2 - (int)(ba << idx.shift) + 1;
             xb2[k] = un[k].p2 - (int)(bb << idx.shift) + 1;
-        }
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef TEC_DIAGNOSTICS
@@ -794,9 +725,9 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
             if (u.boundary || hs.n > kHitSlots) {
                 // (the records carry no CSR offsets: look the lists up again; ch is in range, and a
                 // record with n > 0 means its edge lies inside the chromosome's bins)
-                const uint32_t cbx = ITEMS ? 0u : idx.chrom_base[ch[k]];
-                const uint32_t ga = ITEMS ? iga[k] : cbx + ((uint32_t)u.p1 >> idx.shift);
-                const uint32_t gb = one[k] ? ga : (ITEMS ? igb[k] : cbx + ((uint32_t)u.p2 >> idx.shift));
+                const uint32_t cbx = idx.chrom_base[ch[k]];
+                const uint32_t ga = cbx + ((uint32_t)u.p1 >> idx.shift);
+                const uint32_t gb = one[k] ? ga : cbx + ((uint32_t)u.p2 >> idx.shift);
                 uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
                 if (ra[k].n) { a0 = idx.bin_off[ga]; a1 = idx.bin_off[ga + 1]; }
                 if (one[k]) { b0 = a0; b1 = a1; }
@@ -862,7 +793,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
 #ifdef TEC_DIAGNOSTICS
     if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
 #endif
-    if (!ITEMS && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     // tallies: waves -> workgroup (LDS) -> five global adds per workgroup (4 096 waves adding to one
     // line of memory-side atomics would queue behind each other at the end of the launch)
     __shared__ uint32_t tally[5];
@@ -882,216 +813,14 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     if (threadIdx.x < 5 && tally[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Partitioned pipeline (shuffled batches).  The record kernel on its own pays one 128-byte line
-// fill per random 32-byte record: 7.0 GB of fabric traffic against 1.07 GB of algorithmic bytes.
-// Here the live units are first grouped by genome window (a run of 2^wshift fine bins, at most
-// kPartMaxW windows), so that the count pass works through one window per XCD at a time and the
-// window's records stay in that XCD's L2:
-//   part_hist_kernel     filters + window of every unit, per-workgroup window histogram H[w][g]
-//   part_scan_kernel     exclusive scan of H (window-major), windows dealt to the 8 XCDs by size,
-//                        2048-item chunk lists per XCD
-//   part_scatter_kernel  same unit ranges again: 16-byte items to their slots (LDS cursors from the
-//                        scan: no global atomics, output order deterministic)
-//   count_bulk_rec_kernel<ITEMS>  the record kernel over the items
-// Results are those of the direct kernel bit for bit (same tests on the same units).
-constexpr uint32_t kPartMaxW = 1024;
-constexpr uint32_t kPartChunk = 2048;
-
-struct PartUnit {
-    bool qc, lowq, bad, keep, one;
-    uint32_t ga, gb, win;
-};
-
-// The filters and edge bins of one unit exactly as the record kernel's stage 2 computes them.
-__device__ __forceinline__ PartUnit part_classify(const tec_index_dev& idx, const uint2* chrom_tab, unsigned fl, unsigned mq,
-                                                  int ch, int p1, int p2, int mapq_min, int wshift) {
-    PartUnit u;
-    u.qc = (fl & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) != 0;
-    u.lowq = !u.qc && (int)mq < mapq_min;
-    const bool chrom_ok = (uint32_t)ch < idx.n_chrom;
-    u.bad = !u.qc && !u.lowq && !chrom_ok;
-    const bool live = !u.qc && !u.lowq && chrom_ok;
-    const uint2 t = chrom_tab[chrom_ok ? (uint32_t)ch : 0u];
-    const uint32_t ba = (uint32_t)p1 >> idx.shift, bb = (uint32_t)p2 >> idx.shift;
-    const bool va = live && p1 >= 0 && ba < t.y, vb = live && p2 >= 0 && bb < t.y;
-    u.one = va && vb && ba == bb;
-    u.ga = va ? t.x + ba : idx.zero_rec;
-    u.gb = vb && !u.one ? t.x + bb : idx.zero_rec;
-    u.keep = va || vb;  // a unit with no edge inside the chromosome's bins cannot hit anything
-    u.win = (va ? t.x + ba : t.x + bb) >> wshift;
-    return u;
-}
-
-__device__ __forceinline__ void part_range(uint64_t n, uint64_t* a, uint64_t* b) {
-    uint64_t per = (n + gridDim.x - 1) / gridDim.x;
-    per = (per + 63u) & ~(uint64_t)63u;
-    *a = (uint64_t)blockIdx.x * per;
-    *b = *a + per < n ? *a + per : n;
-    if (*a > n) *a = n;
-}
-
-template <bool SCATTER>
-__global__ __launch_bounds__(kBlock) void part_pass_kernel(tec_index_dev idx, const int32_t* __restrict__ chrom,
-                                                          const int32_t* __restrict__ p1, const int32_t* __restrict__ p2,
-                                                          const uint16_t* __restrict__ flag,
-                                                          const uint8_t* __restrict__ mapq, uint64_t n, int mapq_min,
-                                                          unsigned long long* stats, uint32_t* H, const uint32_t* wstart,
-                                                          uint32_t W, int wshift, uint4* items) {
-    __shared__ uint2 chrom_tab[kChromLds];
-    __shared__ uint32_t cur[kPartMaxW];  // histogram (first pass) / output cursors (second pass)
-    const uint32_t G = gridDim.x;
-    for (uint32_t c = threadIdx.x; c < kChromLds; c += kBlock)
-        chrom_tab[c] = c < idx.n_chrom ? make_uint2(idx.chrom_base[c], idx.chrom_nbins[c]) : make_uint2(0u, 0u);
-    for (uint32_t w = threadIdx.x; w < W; w += kBlock) cur[w] = SCATTER ? wstart[w] + H[(size_t)w * G + blockIdx.x] : 0u;
-    __syncthreads();
-    uint64_t a, b;
-    part_range(n, &a, &b);
-    unsigned w_qc = 0, w_lowq = 0, w_bad = 0;
-    constexpr int PU = 4;  // units per thread in flight
-    for (uint64_t i0 = a; i0 < b; i0 += PU * kBlock) {
-        unsigned fl[PU], mq[PU];
-        int ch[PU], q1[PU], q2[PU];
-        bool live[PU];
-#pragma unroll
-        for (int k = 0; k < PU; ++k) {
-            const uint64_t i = i0 + (uint64_t)k * kBlock + threadIdx.x;
-            live[k] = i < b;
-            const uint64_t ii = live[k] ? i : a;
-            fl[k] = __builtin_nontemporal_load(&flag[ii]);
-            mq[k] = __builtin_nontemporal_load(&mapq[ii]);
-            ch[k] = __builtin_nontemporal_load(&chrom[ii]);
-            q1[k] = __builtin_nontemporal_load(&p1[ii]);
-            q2[k] = __builtin_nontemporal_load(&p2[ii]);
-        }
-#pragma unroll
-        for (int k = 0; k < PU; ++k) {
-            const PartUnit u = part_classify(idx, chrom_tab, fl[k], mq[k], ch[k], q1[k], q2[k], mapq_min, wshift);
-            if (!SCATTER) {
-                w_qc += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live[k] && u.qc));
-                w_lowq += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live[k] && u.lowq));
-                w_bad += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live[k] && u.bad));
-            }
-            if (live[k] && u.keep) {
-                const uint32_t slot = atomicAdd(&cur[u.win], 1u);
-                if (SCATTER) items[slot] = make_uint4(u.ga | (u.one ? 0x80000000u : 0u), u.gb, (uint32_t)q1[k], (uint32_t)q2[k]);
-            }
-        }
-    }
-    if (!SCATTER) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (uint32_t w = threadIdx.x; w < W; w += kBlock) H[(size_t)w * G + blockIdx.x] = cur[w];
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
-        // cur[] has been copied out: its first words carry the workgroup's tallies to one thread
-        __syncthreads();
-        if (threadIdx.x < 3) cur[threadIdx.x] = 0;
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) {
-            if (w_lowq) atomicAdd(&cur[0], w_lowq);
-            if (w_bad) atomicAdd(&cur[1], w_bad);
-            if (w_qc) atomicAdd(&cur[2], w_qc);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x < 3 && cur[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], (unsigned long long)cur[threadIdx.x]);
-    }
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const unsigned lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v += o;
-    }
-    return v;
-}
-
-// One wave per window: row w of H (one count per workgroup of the passes, G a multiple of 512)
-// -> exclusive offsets inside the window, the window's size to wsize_out[w].
-__global__ __launch_bounds__(kBlock) void part_rowscan_kernel(uint32_t* H, uint32_t W, uint32_t G, uint32_t* wsize_out) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
-    if (w >= W) return;
-    uint32_t carry = 0;
-    for (uint32_t g0 = 0; g0 < G; g0 += 512) {  // eight consecutive counts per lane: one round trip per 512
-        uint4* p = reinterpret_cast<uint4*>(H + (size_t)w * G + g0 + lane * 8u);
-        uint4 a = p[0], b = p[1];
-        const uint32_t s0 = a.x, s1 = s0 + a.y, s2 = s1 + a.z, s3 = s2 + a.w, s4 = s3 + b.x, s5 = s4 + b.y, s6 = s5 + b.z,
-                       s7 = s6 + b.w;
-        const uint32_t inc = wave_incl_scan(s7);
-        const uint32_t base = carry + inc - s7;
-        p[0] = make_uint4(base, base + s0, base + s1, base + s2);
-        p[1] = make_uint4(base + s3, base + s4, base + s5, base + s6);
-        carry += (uint32_t)__shfl(inc, 63, 64);
-    }
-    if (lane == 0) wsize_out[w] = carry;
-}
-
-// One workgroup.  Window sizes -> window starts in wstart_out[0..W); every window's items are cut
-// into chunks of kPartChunk, hottest window first, and the chunks are dealt to the eight XCD lists
-// in turn: all XCDs work through the same window at the same time.  pm: TEC_PM_* layout.
-__global__ __launch_bounds__(kBlock) void part_scan_kernel(const uint32_t* wsize_in, uint32_t W, uint32_t* wstart_out, uint32_t* pm) {
-    __shared__ uint32_t wsize[kPartMaxW], wsc[kPartMaxW], wrank[kPartMaxW];
-    __shared__ uint32_t total_chunks;
-    const uint32_t t = threadIdx.x;
-    if (t < kPartMaxW) wsize[t] = t < W ? wsize_in[t] : 0u;
-    __syncthreads();
-    // exclusive scan of the window sizes (W <= 1024: one value per thread)
-    wsc[t] = t < W ? wsize[t] : 0u;
-    __syncthreads();
-    for (uint32_t d = 1; d < kBlock; d <<= 1) {
-        const uint32_t v = t >= d ? wsc[t - d] : 0u;
-        __syncthreads();
-        wsc[t] += v;
-        __syncthreads();
-    }
-    const uint32_t my_size = t < W ? wsize[t] : 0u;
-    const uint32_t my_start = wsc[t] - my_size;
-    if (t < W) wstart_out[t] = my_start;
-    if (t == kBlock - 1) pm[TEC_PM_TOTAL] = wsc[t];
-    // rank by size (largest first), ties by window number; chunks before mine in that order
-    if (t < W) {
-        uint32_t r = 0;
-        for (uint32_t u = 0; u < W; ++u) r += (wsize[u] > my_size || (wsize[u] == my_size && u < t)) ? 1u : 0u;
-        wrank[t] = r;
-    }
-    __syncthreads();
-    uint32_t before = 0;
-    const uint32_t nck = (my_size + kPartChunk - 1) / kPartChunk;
-    if (t < W)
-        for (uint32_t u = 0; u < W; ++u)
-            if (wrank[u] < wrank[t]) before += (wsize[u] + kPartChunk - 1) / kPartChunk;
-    if (t < W && wrank[t] == W - 1) total_chunks = before + nck;
-    __syncthreads();
-    const uint32_t per_xcd = (total_chunks + 7u) / 8u;
-    if (t < 8) {
-        pm[TEC_PM_TICK + t] = 0;
-        pm[TEC_PM_NCHUNKS + t] = total_chunks > t ? (total_chunks - t + 7u) / 8u : 0u;
-        pm[TEC_PM_CBASE + t] = t * per_xcd;
-    }
-    if (t < W)
-        for (uint32_t j = 0; j < nck; ++j) {
-            const uint32_t gci = before + j, x = gci & 7u, pos = x * per_xcd + (gci >> 3);
-            const uint32_t off = j * kPartChunk;
-            pm[TEC_PM_CHUNKS + 2u * pos] = my_start + off;
-            pm[TEC_PM_CHUNKS + 2u * pos + 1u] = my_size - off < kPartChunk ? my_size - off : kPartChunk;
-        }
-}
-
 typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
                                const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t,
                                uint64_t, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*);
 
 template <int U>
 count_kernel_t pick_rec(bool mixed, bool all_lds) {
-    if (all_lds) return mixed ? count_bulk_rec_kernel<true, U, 3, true, false> : count_bulk_rec_kernel<false, U, 3, true, false>;
-    return mixed ? count_bulk_rec_kernel<true, U, 3, false, false> : count_bulk_rec_kernel<false, U, 3, false, false>;
-}
-count_kernel_t pick_items(bool mixed, bool all_lds) {
-    if (all_lds) return mixed ? count_bulk_rec_kernel<true, 2, 3, true, true> : count_bulk_rec_kernel<false, 2, 3, true, true>;
-    return mixed ? count_bulk_rec_kernel<true, 2, 3, false, true> : count_bulk_rec_kernel<false, 2, 3, false, true>;
+    if (all_lds) return mixed ? count_bulk_rec_kernel<true, U, 3, true> : count_bulk_rec_kernel<false, U, 3, true>;
+    return mixed ? count_bulk_rec_kernel<true, U, 3, false> : count_bulk_rec_kernel<false, U, 3, false>;
 }
 template <int U>
 count_kernel_t pick_csr(bool mixed) {
@@ -1190,7 +919,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
             ctx->ev_pool.push_back(p);
         }
     }
-    const bool timed = ctx->partition || ctx->time_every == 1 || (ctx->time_every > 1 && ctx->kernel_launches % (uint64_t)ctx->time_every == 0);
+    const bool timed = ctx->time_every == 1 || (ctx->time_every > 1 && ctx->kernel_launches % (uint64_t)ctx->time_every == 0);
     tec_event_pair& ev = ctx->ev_pool[timed ? ctx->ev_used++ : ctx->ev_used];
     if (timed) ++ctx->timed_launches;
     const int unroll = ctx->unroll;
@@ -1207,7 +936,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const uint32_t spill_lo = name_bits > 8 ? std::min(name_bits - 8, 14u) : 0u;
     const uint32_t n_buckets = (ctx->idx.n_names + (1u << spill_lo) - 1u) >> spill_lo;
     const bool may_spill = ctx->idx.n_names > budget / 2 && ctx->spill_enabled && n_buckets <= 1024 && ctx->kernel_variant == 2 &&
-                           ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3 && !ctx->partition;
+                           ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3;
     if (may_spill) budget -= (n_buckets * 4u + 15u) & ~15u;
     const uint32_t k_lds = std::min<uint32_t>(ctx->idx.n_names, budget / 2);
     const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;  // as the kernels compute it
@@ -1236,89 +965,28 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     const bool rec_ok = ctx->kernel_variant == 2 && ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3;
     unsigned rows = grid;  // histogram rows of this launch
     uint32_t* const slab = ctx->d_slabs + (size_t)ctx->slab_slot * ctx->n_cu * words;
-    if (ctx->partition && rec_ok && unroll == 2 && (n >= (1u << 16) || ctx->partition == 2) && n < 0xFFFF0000ull) {
-        TEC_HIP(ctx, hipEventRecord(ev.start, ctx->s_compute));
-        // ---- partitioned pipeline: histogram, scan, scatter, count over the items
-        int wshift = ctx->part_wshift;
-        if (wshift <= 0) {
-            wshift = 0;
-            while (((ctx->n_bins >> wshift) + 1) > 512) ++wshift;
-        }
-        while (((ctx->n_bins >> wshift) + 1) > kPartMaxW) ++wshift;
-        const uint32_t W = (uint32_t)(ctx->n_bins >> wshift) + 1;
-        const uint32_t G = (2u * (uint32_t)ctx->n_cu + 511u) / 512u * 512u;  // ~two workgroups of the passes per CU; whole 512s for the row scan
-        const size_t need_items = (size_t)n * sizeof(uint4);
-        const size_t need_h = ((size_t)W * G + 2 * kPartMaxW + 8) * sizeof(uint32_t);  // + the window starts and sizes
-        const size_t need_pm = (size_t)(TEC_PM_CHUNKS + 2 * (n / kPartChunk + W + 64)) * sizeof(uint32_t);
-        if (need_items > ctx->part_items_cap || need_h > ctx->part_h_cap || need_pm > ctx->part_pm_cap) {
-            TEC_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
-            if (need_items > ctx->part_items_cap) {
-                if (ctx->d_part_items) TEC_HIP(ctx, hipFree(ctx->d_part_items));
-                ctx->d_part_items = nullptr;
-                ctx->part_items_cap = 0;
-                TEC_HIP(ctx, hipMalloc(&ctx->d_part_items, need_items));
-                ctx->part_items_cap = need_items;
-            }
-            if (need_h > ctx->part_h_cap) {
-                if (ctx->d_part_h) TEC_HIP(ctx, hipFree(ctx->d_part_h));
-                ctx->d_part_h = nullptr;
-                ctx->part_h_cap = 0;
-                TEC_HIP(ctx, hipMalloc(&ctx->d_part_h, need_h));
-                ctx->part_h_cap = need_h;
-            }
-            if (need_pm > ctx->part_pm_cap) {
-                if (ctx->d_part_pm) TEC_HIP(ctx, hipFree(ctx->d_part_pm));
-                ctx->d_part_pm = nullptr;
-                ctx->part_pm_cap = 0;
-                TEC_HIP(ctx, hipMalloc(&ctx->d_part_pm, need_pm));
-                ctx->part_pm_cap = need_pm;
-            }
-        }
-        rows = (unsigned)ctx->n_cu;
-        uint32_t* H = static_cast<uint32_t*>(ctx->d_part_h);
-        uint32_t* pm = static_cast<uint32_t*>(ctx->d_part_pm);
-        uint4* items = static_cast<uint4*>(ctx->d_part_items);
-        uint32_t* wstart = H + (size_t)W * G;
-        hipLaunchKernelGGL(part_pass_kernel<false>, dim3(G), dim3(kBlock), 0, ctx->s_compute, ctx->idx, u.chrom, u.p1, u.p2,
-                           u.flag, u.mapq, n, ctx->mapq_min, ctx->d_stats, H, wstart, W, wshift, items);
-        uint32_t* wsize = wstart + kPartMaxW;
-        hipLaunchKernelGGL(part_rowscan_kernel, dim3((W + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, ctx->s_compute, H, W, G,
-                           wsize);
-        hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(kBlock), 0, ctx->s_compute, (const uint32_t*)wsize, W, wstart, pm);
-        hipLaunchKernelGGL(part_pass_kernel<true>, dim3(G), dim3(kBlock), 0, ctx->s_compute, ctx->idx, u.chrom, u.p1, u.p2,
-                           u.flag, u.mapq, n, ctx->mapq_min, ctx->d_stats, H, wstart, W, wshift, items);
-        TEC_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(pick_items(mixed, k_lds >= ctx->idx.n_names), dim3(ctx->n_cu), dim3(kBlock), lds, ctx->s_compute,
-                           ctx->idx, reinterpret_cast<const int32_t*>(items), reinterpret_cast<const int32_t*>(pm),
-                           (const int32_t*)nullptr, (const uint16_t*)nullptr, (const uint8_t*)nullptr, (uint64_t)0,
-                           ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, (uint64_t)1, (uint32_t)ctx->aggregate,
-                           slab, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
-        TEC_HIP(ctx, hipGetLastError());
-        TEC_HIP(ctx, hipEventRecord(ev.stop, ctx->s_compute));
-    } else {
-        // start / stop timestamps ride on the dispatch itself: no barrier packets between the launches
-        // names beyond the LDS histogram go to a bucketed spill list (see FastSink), folded right after the launch
-        const bool spilling = may_spill && rec_ok && k_lds < ctx->idx.n_names;
-        uint32_t spill_cap = 0;
-        if (spilling) {
-            // room for three names per unit, spread over the buckets (a unit adds at most six on the fast path,
-            // config 5 averages 1.45); a slice that fills up falls back to global atomics
-            const uint64_t per_wg = (n + grid - 1) / grid;
-            spill_cap = (uint32_t)std::min<uint64_t>((per_wg * 3 + n_buckets - 1) / n_buckets + 64, 0xFFFFFFull);
-            int rc = tec_spill_reserve(ctx, grid, n_buckets, spill_cap);
-            if (rc) return rc;
-        }
-        hipExtLaunchKernelGGL(pick_kernel(mixed, unroll, rec_ok ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid),
-                              dim3(kBlock), (uint32_t)lds, ctx->s_compute, timed ? ev.start : (hipEvent_t) nullptr,
-                              timed ? ev.stop : (hipEvent_t) nullptr, 0u, ctx->idx, u.chrom, u.p1, u.p2,
-                              u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                              (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
-                              spill_cap | (spill_lo << 24), ctx->d_spill_counts);
-        TEC_HIP(ctx, hipGetLastError());
-        if (spilling) {
-            int rc = tec_spill_fold(ctx, grid, n_buckets, spill_lo, spill_cap);
-            if (rc) return rc;
-        }
+    // start / stop timestamps ride on the dispatch itself: no barrier packets between the launches
+    // names beyond the LDS histogram go to a bucketed spill list (see FastSink), folded right after the launch
+    const bool spilling = may_spill && rec_ok && k_lds < ctx->idx.n_names;
+    uint32_t spill_cap = 0;
+    if (spilling) {
+        // room for three names per unit, spread over the buckets (a unit adds at most six on the fast path,
+        // config 5 averages 1.45); a slice that fills up falls back to global atomics
+        const uint64_t per_wg = (n + grid - 1) / grid;
+        spill_cap = (uint32_t)std::min<uint64_t>((per_wg * 3 + n_buckets - 1) / n_buckets + 64, 0xFFFFFFull);
+        int rc = tec_spill_reserve(ctx, grid, n_buckets, spill_cap);
+        if (rc) return rc;
+    }
+    hipExtLaunchKernelGGL(pick_kernel(mixed, unroll, rec_ok ? ctx->rec_ne : 0, k_lds >= ctx->idx.n_names), dim3(grid),
+                          dim3(kBlock), (uint32_t)lds, ctx->s_compute, timed ? ev.start : (hipEvent_t) nullptr,
+                          timed ? ev.stop : (hipEvent_t) nullptr, 0u, ctx->idx, u.chrom, u.p1, u.p2,
+                          u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
+                          (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
+                          spill_cap | (spill_lo << 24), ctx->d_spill_counts);
+    TEC_HIP(ctx, hipGetLastError());
+    if (spilling) {
+        int rc = tec_spill_fold(ctx, grid, n_buckets, spill_lo, spill_cap);
+        if (rc) return rc;
     }
     // the rows wait in their slot; one reduce folds kSlabSlots launches (or what is pending at the next sync)
     ctx->slab_used[ctx->slab_slot++] = rows;
@@ -1340,10 +1008,6 @@ int tec_bulk_init(tec_ctx* ctx) {
                 for (int all = 0; all < 2; ++all)
                     TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec, all != 0)),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)(kChromLds * sizeof(uint2)) - 64));
-    for (int mixed = 0; mixed < 2; ++mixed)
-        for (int all = 0; all < 2; ++all)
-            TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_items(mixed != 0, all != 0)),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)(kChromLds * sizeof(uint2)) - 64));
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
@@ -1366,10 +1030,6 @@ int tec_bulk_init(tec_ctx* ctx) {
     ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 154 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
     e = getenv("TEC_TIME_EVERY");  // experiment: timestamp only every k-th count launch (0 = never)
     ctx->time_every = e ? atoi(e) : 1;
-    e = getenv("TEC_PARTITION");  // 1: group the live units by genome window before counting (shuffled batches)
-    ctx->partition = e ? atoi(e) : 0;  // 2: also for tiny batches (tests)
-    e = getenv("TEC_PART_WSHIFT");  // tuning knob: log2(fine bins per window), 0 = automatic
-    ctx->part_wshift = e ? atoi(e) : 0;
     e = getenv("TEC_SPILL");  // 0: names beyond the LDS histogram are counted with global atomics (the round-1 path)
     ctx->spill_enabled = !(e && atoi(e) == 0);
     e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
@@ -1400,11 +1060,6 @@ int tec_bulk_release(tec_ctx* ctx) {
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     ctx->d_slabs = nullptr;
     ctx->slab_cap = 0;
-    if (ctx->d_part_items) (void)hipFree(ctx->d_part_items);
-    if (ctx->d_part_h) (void)hipFree(ctx->d_part_h);
-    if (ctx->d_part_pm) (void)hipFree(ctx->d_part_pm);
-    ctx->d_part_items = ctx->d_part_h = ctx->d_part_pm = nullptr;
-    ctx->part_items_cap = ctx->part_h_cap = ctx->part_pm_cap = 0;
     return TEC_OK;
 }
 

@@ -6,7 +6,7 @@
 // chunk.  Everything else runs on the MI355X:
 //
 //   ginflate_kernel     one lane inflates one BGZF block (ginflate.h: 16-bit Huffman tables in LDS,
-//                       1152 B per lane -> 128 lanes per CU); a block the kernel refuses is redone by
+//                       672 B per lane -> 192 lanes per CU); a block the kernel refuses is redone by
 //                       the host's referee decoder (inflate_fast.h, then zlib) and patched in
 //   seg_guess_kernel    the inflated stream is cut into 64 KiB segments; one wave per segment looks for
 //                       the first offset at which a chain of BAM records plausibly starts (bamscan.h)
@@ -48,7 +48,10 @@ constexpr uint32_t kSeg = 1u << kSegShift;
 constexpr uint32_t kMaxRecPerSeg = kSeg / 36u + 2u;  // a record is at least 36 bytes with its size field
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one chunk to the next
-constexpr int kInflThreads = 128;        // lanes per workgroup of the inflate kernel = lanes per CU (LDS bound)
+#ifndef TEC_GINF_THREADS
+#define TEC_GINF_THREADS 192
+#endif
+constexpr int kInflThreads = TEC_GINF_THREADS;        // lanes per workgroup of the inflate kernel = lanes per CU (LDS bound)
 constexpr uint32_t kFlagFilter = TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP;
 
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -59,8 +62,9 @@ struct BlockDesc {
 };
 
 // ---- per-lane memory of the inflate kernel: tables in LDS, lane-interleaved (entry i of lane L at
-// u16 index i * 128 + L: same-i accesses of a wave are consecutive, random-i accesses always land
-// in the lane pair's own bank); the symbols of long codes in global memory, interleaved per wave
+// u16 index i * 192 + L: same-i accesses of a wave are consecutive, random-i accesses land in the
+// lane pair's own bank, shifted by half the banks for odd i); the symbols of long codes in global
+// memory, interleaved per wave
 struct DevMem {
     uint16_t* t;
     uint16_t* s;
@@ -288,9 +292,9 @@ struct tec_gbam : GbamBuffers {
     uint64_t first_data_off = 0;     // file offset of the first BGZF block this reader stages
     uint64_t hdr_block_off = 0;      // range 0: block that holds the first record ...
     uint32_t hdr_inblock = 0;        // ... and its offset inside that block's inflated bytes
-    // one chunk = one launch of the inflate kernel: 128 lanes x 256 CUs = 32768 blocks fill the chip exactly once
+    // one chunk = one launch of the inflate kernel: 192 lanes x 256 CUs = 49152 blocks fill the chip exactly once
     size_t chunk_bytes = 2047u << 20;
-    uint32_t chunk_blocks = 32768;
+    uint32_t chunk_blocks = 256u * kInflThreads;
     int read_threads = 8;
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
@@ -438,8 +442,9 @@ struct RunState {
 };
 
 int ensure_records(tec_gbam* g, uint64_t rows, int mode, bool keep, uint64_t used_rows) {
-    if (rows <= g->r_cap) return TEC_OK;
-    const uint64_t want = keep ? std::max<uint64_t>(rows, g->r_cap * 2) : rows + rows / 8 + 1024;
+    // (the buffers outlive one file -- they are cached on the context -- and a later run may be of another mode:
+    // every array the mode uses is brought to the common row capacity, the others stay as they are)
+    const uint64_t want = rows <= g->r_cap ? g->r_cap : (keep ? std::max<uint64_t>(rows, g->r_cap * 2) : rows + rows / 8 + 1024);
     auto grow = [&](DBuf& b, size_t elt) { return b.reserve((size_t)want * elt, keep, (size_t)used_rows * elt); };
     G_HIP(grow(g->r_chrom, 4));
     G_HIP(grow(g->r_pos, 4));

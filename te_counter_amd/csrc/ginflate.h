@@ -6,8 +6,10 @@
 // the number of lanes per CU is table memory, and what limits a lane's speed is the number of
 // global-memory round trips on its critical path (on gfx9 loads and stores retire in order through one
 // counter, so a load that follows a store waits for that store).  Hence:
-//   * tables are small and 16-bit, in LDS: literal/length 9-bit first level (512 entries), distance
-//     6-bit (64) -- plus 16 spare entries = 1184 bytes per lane -> 128 lanes per CU in 148 KiB;
+//   * tables are small and 16-bit, in LDS: literal/length 8-bit first level (256 entries), distance
+//     6-bit (64) -- plus 16 spare entries = 672 bytes per lane -> 192 lanes (three waves) per CU in
+//     126 KiB.  (A 9-bit first level -- 1184 bytes, 128 lanes -- decodes a block 10 % faster, but a
+//     launch holds a third fewer blocks: 48 M-record file 0.56 s -> 0.47 s with the 8-bit level);
 //   * the code lengths of a dynamic block are kept as nibbles in the (not yet built) distance-table
 //     area, so that building the tables touches LDS and registers only;
 //   * codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit,
@@ -37,12 +39,15 @@
 
 namespace tec_ginf {
 
-constexpr int kLitRoot = 9;
+#ifndef TEC_GINF_LITROOT
+#define TEC_GINF_LITROOT 8
+#endif
+constexpr int kLitRoot = TEC_GINF_LITROOT;
 constexpr int kDistRoot = 6;
 constexpr uint32_t kLitEntries = 1u << kLitRoot;
 constexpr uint32_t kDistEntries = 1u << kDistRoot;
-constexpr uint32_t kLenArea = kLitEntries;                            // nibble store of the code lengths: entries [512, 592)
-constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries + 16u;  // u16 each: 1184 bytes
+constexpr uint32_t kLenArea = kLitEntries;                            // nibble store of the code lengths: 80 entries behind the literal/length table
+constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries + 16u;  // u16 each: 672 bytes
 constexpr uint32_t kLongSymsPerLane = 320;                            // symbols of codes longer than the first level (u16, global)
 constexpr uint32_t kInPad = 16;                                       // readable bytes the caller guarantees behind the input
 

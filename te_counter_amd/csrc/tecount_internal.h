@@ -88,11 +88,6 @@ struct tec_ctx {
     uint32_t slab_words = 0;
     std::vector<tec_event_pair> red_pool;  // start / stop of the reduce kernels
     size_t red_used = 0;
-    // partitioned pipeline (bulk.hip): items grouped by genome window, window x workgroup offsets, chunk lists
-    int partition = 0;
-    int part_wshift = 0;
-    void *d_part_items = nullptr, *d_part_h = nullptr, *d_part_pm = nullptr;
-    size_t part_items_cap = 0, part_h_cap = 0, part_pm_cap = 0;
     uint64_t kernel_launches = 0, timed_launches = 0;
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel

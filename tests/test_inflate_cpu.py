@@ -1,4 +1,5 @@
-"""The BAM reader's own DEFLATE decoder (csrc/inflate_fast.h) against zlib: every stream zlib can
+"""The BAM reader's own DEFLATE decoders against zlib -- csrc/inflate_fast.h (host decoder) and the host
+build of csrc/ginflate.h (what one GPU lane runs in the on-GPU front end): every stream zlib can
 produce for blocks up to 64 KiB must decode to the same bytes, and damaged streams must be
 refused (or decode to something zlib agrees with) without touching memory outside the buffers."""
 
@@ -11,14 +12,21 @@ import pytest
 from te_counter_amd import _lib
 
 
-def _inflate(comp, n, use_zlib=0):
+HOST, ZLIB, LANE = 0, 1, 2   # tec_inflate_raw's decoders
+DECODERS = pytest.mark.parametrize('decoder', [HOST, LANE], ids=['host', 'gpu_lane'])
+
+
+def _inflate(comp, n, decoder=HOST, shift=0):
+    """shift: misalignment of the output address (the lane decoder copies matches in 8-byte groups)."""
     lib = _lib.load()
-    out = (C.c_uint8 * (n + 64))()
+    out = (C.c_uint8 * (n + 128 + shift))()
     guard = bytes(range(64))
-    C.memmove(C.addressof(out) + n, guard, 64)
-    rc = lib.tec_inflate_raw(comp, len(comp), out, n, use_zlib)
-    assert bytes(out[n:n + 64]) == guard, 'wrote past the output buffer'
-    return rc, bytes(out[:n])
+    C.memmove(C.addressof(out) + shift, guard, 64)
+    C.memmove(C.addressof(out) + shift + 64 + n, guard, 64)
+    dst = C.cast(C.addressof(out) + shift + 64, C.c_void_p)
+    rc = lib.tec_inflate_raw(comp, len(comp), dst, n, decoder)
+    assert bytes(out[shift:shift + 64]) == guard and bytes(out[shift + 64 + n:shift + 128 + n]) == guard, 'wrote outside the output buffer'
+    return rc, bytes(out[shift + 64:shift + 64 + n])
 
 
 def _payloads():
@@ -47,19 +55,21 @@ def _payloads():
 
 @pytest.mark.parametrize('level,strategy', [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
                                             (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (0, zlib.Z_DEFAULT_STRATEGY)])
-def test_matches_zlib(level, strategy):
-    for data in _payloads():
-        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+@DECODERS
+def test_matches_zlib(level, strategy, decoder):
+    for k, data in enumerate(_payloads()):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 1 if k % 5 == 4 else 9, strategy)
         comp = co.compress(data) + co.flush()
-        rc, got = _inflate(comp, len(data))
+        rc, got = _inflate(comp, len(data), decoder, shift=k % 16)
         assert rc == 0 and got == data, (level, strategy, len(data))
         # wrong expected sizes are refused
         if len(data) > 1:
-            assert _inflate(comp, len(data) - 1)[0] != 0
-        assert _inflate(comp, len(data) + 1)[0] != 0
+            assert _inflate(comp, len(data) - 1, decoder)[0] != 0
+        assert _inflate(comp, len(data) + 1, decoder)[0] != 0
 
 
-def test_multi_block_streams():
+@DECODERS
+def test_multi_block_streams(decoder):
     rng = np.random.default_rng(9)
     for _ in range(20):
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
@@ -70,11 +80,12 @@ def test_multi_block_streams():
             comp += co.compress(d) + co.flush(zlib.Z_FULL_FLUSH if rng.random() < 0.5 else zlib.Z_SYNC_FLUSH)
         comp += co.flush()
         data = b''.join(parts)
-        rc, got = _inflate(comp, len(data))
+        rc, got = _inflate(comp, len(data), decoder)
         assert rc == 0 and got == data
 
 
-def test_damaged_streams_never_disagree_with_zlib():
+@DECODERS
+def test_damaged_streams_never_disagree_with_zlib(decoder):
     rng = np.random.default_rng(13)
     base = bytes(rng.integers(0, 20, 20000, dtype=np.uint8))
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
@@ -90,8 +101,8 @@ def test_damaged_streams_never_disagree_with_zlib():
         else:
             for _ in range(4):
                 b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
-        rc, got = _inflate(bytes(b), len(base))
-        zrc, zgot = _inflate(bytes(b), len(base), use_zlib=1)
+        rc, got = _inflate(bytes(b), len(base), decoder, shift=trial % 16)
+        zrc, zgot = _inflate(bytes(b), len(base), ZLIB)
         if rc == 0:  # whatever the fast decoder accepts, zlib decodes to the same bytes
             accepted += 1
             assert zrc == 0 and zgot == got
