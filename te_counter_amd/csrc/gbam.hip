@@ -303,6 +303,7 @@ struct tec_gbam : GbamBuffers {
     uint64_t tok_first[2] = {0, 0}, tok_end[2] = {0, 0};
     uint64_t blocks = 0, blocks_host = 0, comp_bytes = 0, infl_bytes = 0, repairs = 0;
     double t_stage_wait = 0, t_inflate = 0, t_segments = 0, t_rows = 0;  // seconds of the decode loop, by phase
+    double mean_block_bytes = 0;  // compressed bytes per BGZF block, from the chunks staged so far
     double t_stage_alloc = 0, t_stage_read = 0;                          // staging thread: pinned allocation, pread
     // deferred PE pairing
     bool deferred = false;
@@ -343,7 +344,23 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         st->last = st->at_eof = true;
         return;
     }
-    const size_t want = (size_t)std::min<uint64_t>(g->chunk_bytes + 65536 + 64, g->file_size - off);
+    // window of the file to stage: what max_blocks blocks are expected to need (+ 6 %), from the mean block size seen so far
+    // -- before the first chunk, from a 4 MiB probe at `off`.  A window that turns out short just ends the chunk early.
+    if (g->mean_block_bytes <= 0) {
+        std::vector<uint8_t> probe((size_t)std::min<uint64_t>(4u << 20, g->file_size - off) + 32, 0);
+        const ssize_t k = pread(g->fd, probe.data(), probe.size() - 32, (off_t)off);
+        size_t o = 0, bsize, body_off, body_len;
+        uint32_t isize, nb = 0;
+        while (k > 0 && tec_bgzf_parse(probe.data(), (size_t)k, o, &bsize, &body_off, &body_len, &isize)) {
+            o += bsize;
+            ++nb;
+        }
+        g->mean_block_bytes = nb ? (double)o / nb : 65536.0;
+    }
+    const uint64_t expect = (uint64_t)(g->mean_block_bytes * 1.06 * max_blocks) + (1u << 20);
+    size_t want = (size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off);
+    // (pinning costs ~0.1 s per GB: a buffer that is a little short is used as it is rather than replaced)
+    if (st->pinned_cap && want + 32 > st->pinned_cap && want < st->pinned_cap + st->pinned_cap / 4) want = st->pinned_cap - 32;
     double t0 = now_s();
     if (want + 32 > st->pinned_cap) {
         if (st->pinned) (void)hipHostFree(st->pinned);
@@ -413,6 +430,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
     }
     st->bytes = o;
     st->inflated = infl;
+    if (!st->desc.empty()) g->mean_block_bytes = (double)o / (double)st->desc.size();
     st->next_off = off + o;
     if (st->next_off >= g->file_size) st->last = st->at_eof = true;
     if (st->next_off >= limit) st->last = true;

@@ -22,11 +22,45 @@ class Engine:
         self.device = int(device)
         self.n_names = 0
         self._keep = []  # host arrays of in-flight submits
+        self._pinned = []  # (address, ctypes buffer) of every tec_alloc_pinned block: freed at close()
+        self._ring, self._ring_cap, self._ring_slot = None, 0, 0
 
     def close(self):
         if self._ctx:
+            self._keep, self._ring = [], None
+            for addr, _ in self._pinned:
+                self._lib.tec_free_pinned(self._ctx, C.c_void_p(addr))
+            self._pinned = []
             self._lib.tec_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def pinned_empty(self, n, dtype):
+        """A numpy array over page-locked host memory (tec_alloc_pinned): hipMemcpyAsync from it really is
+        asynchronous.  The memory belongs to the engine and is released by close()."""
+        dtype = np.dtype(dtype)
+        nbytes = max(1, int(n) * dtype.itemsize)
+        p = C.c_void_p()
+        self._check(self._lib.tec_alloc_pinned(self._ctx, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        self._pinned.append((p.value, buf))
+        return np.frombuffer(buf, np.uint8, int(n) * dtype.itemsize).view(dtype)
+
+    def _staging_slot(self, n):
+        """One of three pinned SoA slots of at least n units (the same ring depth as the device side)."""
+        if n > self._ring_cap:
+            cap = max(int(n), 1 << 16)
+            if self._ring:  # (the caller has drained the copies out of the old slots)
+                old = {a.ctypes.data for slot in self._ring for a in slot}
+                self._ring = None
+                for addr, _ in [e for e in self._pinned if e[0] in old]:
+                    self._lib.tec_free_pinned(self._ctx, C.c_void_p(addr))
+                self._pinned = [e for e in self._pinned if e[0] not in old]
+            self._ring = [tuple(self.pinned_empty(cap, dt) for dt in (np.int32, np.int32, np.int32, np.uint16, np.uint8))
+                          for _ in range(3)]
+            self._ring_cap = cap
+        slot = self._ring[self._ring_slot]
+        self._ring_slot = (self._ring_slot + 1) % 3
+        return slot
 
     def __del__(self):
         try:
@@ -55,14 +89,25 @@ class Engine:
         self._keep = []
         self._check(self._lib.tec_bulk_begin(self._ctx, int(mapq_min)))
 
-    def bulk_submit(self, chrom, p1, p2, flag, mapq):
-        """Host SoA batch (numpy).  Arrays are kept alive until bulk_finish / bulk_sync."""
+    def bulk_submit(self, chrom, p1, p2, flag, mapq, stage=True):
+        """Host SoA batch (numpy).  stage=True: the batch is copied into one of three page-locked slots
+        (tec_alloc_pinned) first, so that the call returns while the copy to HBM is still running and the
+        caller may reuse its arrays at once; stage=False: the arrays are handed over as they are (callers
+        that build their batches in pinned_empty() arrays) and kept alive until their copy has finished."""
         arrs = (np.ascontiguousarray(chrom, np.int32), np.ascontiguousarray(p1, np.int32),
                 np.ascontiguousarray(p2, np.int32), np.ascontiguousarray(flag, np.uint16),
                 np.ascontiguousarray(mapq, np.uint8))
         n = len(arrs[0])
         if any(len(a) != n for a in arrs):
             raise ValueError('unit arrays differ in length')
+        if stage and n:
+            if n > self._ring_cap:  # the slots are replaced: nothing may still be copying out of the old ones
+                self._check(self._lib.tec_bulk_sync(self._ctx))
+                self._keep = []
+            slot = self._staging_slot(n)
+            for dst, src in zip(slot, arrs):
+                dst[:n] = src
+            arrs = tuple(dst[:n] for dst in slot)
         t = C.c_uint64()
         self._check(self._lib.tec_bulk_submit(self._ctx, n, *[_ptr(a) for a in arrs], C.byref(t)))
         self._keep.append(arrs)

@@ -32,7 +32,7 @@ def main():
     src, tag, key = sys.argv[1], sys.argv[2], sys.argv[3]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {'tag': tag, 'workload': key, 'bench_args': open(os.path.join(src, 'bench_args.txt')).read().strip(),
-           'command': 'rocprofv3 <flags> -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-host-stream <bench_args>'}
+           'command': 'rocprofv3 <flags> -- python3 bench.py --legs headline --steps 5 --warmup 1 <bench_args>'}
     stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
@@ -48,6 +48,13 @@ def main():
             n.update(c)
     out['pmc_mean_per_dispatch'] = pmc
     out['pmc_dispatches'] = n
+    # config 5: the fold of the spill list (csrc/spill.hip) runs behind every count launch
+    fold = {}
+    for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
+        if os.path.isdir(d):
+            fold.update(kernel_means(d, 'spill_bucket')[0])
+    if fold:
+        out['pmc_mean_per_dispatch_spill_bucket_kernel'] = fold
     if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
         rd = pmc['FETCH_SIZE'] * 1024 + 64 * pmc.get('TCC_EA0_RDREQ_128B_sum', 0.0)
         wr = pmc['WRITE_SIZE'] * 1024
