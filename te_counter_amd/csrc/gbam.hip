@@ -6,7 +6,7 @@
 // chunk.  Everything else runs on the MI355X:
 //
 //   ginflate_kernel     one lane inflates one BGZF block (ginflate.h: 16-bit Huffman tables in LDS,
-//                       672 B per lane -> 192 lanes per CU); a block the kernel refuses is redone by
+//                       640 B per lane -> 256 lanes per CU); a block the kernel refuses is redone by
 //                       the host's referee decoder (inflate_fast.h, then zlib) and patched in
 //   seg_guess_kernel    the inflated stream is cut into 64 KiB segments; one wave per segment looks for
 //                       the first offset at which a chain of BAM records plausibly starts (bamscan.h)
@@ -49,8 +49,9 @@ constexpr uint32_t kMaxRecPerSeg = kSeg / 36u + 2u;  // a record is at least 36 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one chunk to the next
 #ifndef TEC_GINF_THREADS
-#define TEC_GINF_THREADS 192
+#define TEC_GINF_THREADS 256
 #endif
+constexpr size_t kScratchPerWave = 64u * (tec_ginf::kLongSymsPerLane * 2u + tec_ginf::kLenWords * 8u);  // global scratch of the inflate kernel
 constexpr int kInflThreads = TEC_GINF_THREADS;        // lanes per workgroup of the inflate kernel = lanes per CU (LDS bound)
 constexpr uint32_t kFlagFilter = TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP;
 
@@ -62,12 +63,15 @@ struct BlockDesc {
 };
 
 // ---- per-lane memory of the inflate kernel: tables in LDS, lane-interleaved (entry i of lane L at
-// u16 index i * 192 + L: same-i accesses of a wave are consecutive, random-i accesses land in the
-// lane pair's own bank, shifted by half the banks for odd i); the symbols of long codes in global
-// memory, interleaved per wave
+// u16 index i * 256 + L: same-i accesses of a wave are consecutive, random-i accesses always land
+// in the lane pair's own bank); the symbols of long codes and the code lengths of the block being
+// set up in global memory, interleaved per wave
 struct DevMem {
     uint16_t* t;
     uint16_t* s;
+    uint64_t* w;  // code lengths of the dynamic block being set up, 16 per word, interleaved per wave like s
+    __device__ __forceinline__ uint64_t lenw(uint32_t k) const { return w[k * 64u]; }
+    __device__ __forceinline__ void set_lenw(uint32_t k, uint64_t v) { w[k * 64u] = v; }
     __device__ __forceinline__ uint32_t tab(uint32_t i) const { return t[i * kInflThreads]; }
     __device__ __forceinline__ void set_tab(uint32_t i, uint32_t v) { t[i * kInflThreads] = (uint16_t)v; }
     __device__ __forceinline__ uint32_t sym(uint32_t i) const { return s[i * 64u]; }
@@ -81,7 +85,9 @@ __global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1,
     const uint32_t b = blockIdx.x * kInflThreads + threadIdx.x;
     if (b >= n) return;
     const size_t wave = b >> 6, lane = b & 63u;
-    DevMem m{lds_tab + threadIdx.x, syms_scr + wave * 64u * tec_ginf::kLongSymsPerLane + lane};
+    uint8_t* const scr = reinterpret_cast<uint8_t*>(syms_scr) + wave * kScratchPerWave;
+    DevMem m{lds_tab + threadIdx.x, reinterpret_cast<uint16_t*>(scr) + lane,
+             reinterpret_cast<uint64_t*>(scr + 64u * tec_ginf::kLongSymsPerLane * 2u) + lane};
     const BlockDesc d = desc[b];
     int rc = tec_ginf::kOk;
     if (d.isize) rc = tec_ginf::inflate_stream(comp + d.in_off, d.in_len, infl + d.out_off, d.isize, m);
@@ -264,6 +270,9 @@ struct Staged {  // one chunk of compressed blocks in pinned host memory
     bool last = false;          // no owned block follows
     bool at_eof = false;        // next_off is the end of the file
     std::string error;
+    // the staging thread also starts the chunk's copy to HBM (copy stream): it overlaps the GPU's work on the chunk before
+    DBuf d_comp, d_desc;
+    hipEvent_t copied = nullptr;
 };
 
 }  // namespace
@@ -272,7 +281,7 @@ struct Staged {  // one chunk of compressed blocks in pinned host memory
 // context (allocating and freeing gigabytes of HBM and pinned memory costs more than decoding a small file),
 // the next reader on that context takes them over, tec_destroy frees them.
 struct GbamBuffers {
-    DBuf d_comp, d_desc, d_infl, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
+    DBuf d_infl, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
     DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
     DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
     DBuf d_flags;
@@ -292,7 +301,7 @@ struct tec_gbam : GbamBuffers {
     uint64_t first_data_off = 0;     // file offset of the first BGZF block this reader stages
     uint64_t hdr_block_off = 0;      // range 0: block that holds the first record ...
     uint32_t hdr_inblock = 0;        // ... and its offset inside that block's inflated bytes
-    // one chunk = one launch of the inflate kernel: 192 lanes x 256 CUs = 49152 blocks fill the chip exactly once
+    // one chunk = one launch of the inflate kernel: 256 lanes x 256 CUs = 65536 blocks fill the chip exactly once
     size_t chunk_bytes = 2047u << 20;
     uint32_t chunk_blocks = 256u * kInflThreads;
     int read_threads = 8;
@@ -434,6 +443,16 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
     st->next_off = off + o;
     if (st->next_off >= g->file_size) st->last = st->at_eof = true;
     if (st->next_off >= limit) st->last = true;
+    if (!st->desc.empty() && st->error.empty()) {  // compressed bytes + block descriptors on their way to HBM
+        hipStream_t cp = g->ctx->s_copy;
+        hipError_t e = st->copied ? hipSuccess : hipEventCreateWithFlags(&st->copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = st->d_comp.reserve(st->bytes + 64);
+        if (e == hipSuccess) e = st->d_desc.reserve(st->desc.size() * sizeof(BlockDesc));
+        if (e == hipSuccess) e = hipMemcpyAsync(st->d_comp.p, st->pinned, st->bytes + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
+        if (e == hipSuccess) e = hipMemcpyAsync(st->d_desc.p, st->desc.data(), st->desc.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, cp);
+        if (e == hipSuccess) e = hipEventRecord(st->copied, cp);
+        if (e != hipSuccess) st->error = std::string("copy of a staged chunk to the GPU failed: ") + hipGetErrorString(e);
+    }
 }
 
 struct ChunkResult {
@@ -530,11 +549,9 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     res->tail = total;
     if (total == 0) return TEC_OK;
     // ---- device buffers
-    G_HIP(g->d_comp.reserve(st->bytes + 64));
-    G_HIP(g->d_desc.reserve((size_t)std::max(nb, 1u) * sizeof(BlockDesc)));
     G_HIP(g->d_infl.reserve(kCarryMax + st->inflated + 256, true, kCarryMax));  // keep: the carry sits below kCarryMax
     const uint32_t waves = (nb + 63u) / 64u;
-    G_HIP(g->d_syms.reserve((size_t)std::max(waves, 1u) * 64u * tec_ginf::kLongSymsPerLane * 2));
+    G_HIP(g->d_syms.reserve((size_t)std::max(waves, 1u) * kScratchPerWave));
     G_HIP(g->d_ctl.reserve(64 + (size_t)std::max(nb, 1u) * 4));
     uint32_t* d_nfailed = g->d_ctl.as<uint32_t>();
     uint32_t* d_failed = d_nfailed + 16;
@@ -542,12 +559,11 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     uint8_t* d_stream = d_stream_base - carry;                     // stream offset 0
     double t0 = now_s();
     if (nb) {
-        G_HIP(hipMemcpyAsync(g->d_comp.p, st->pinned, st->bytes + tec_ginf::kInPad, hipMemcpyHostToDevice, cs));
-        G_HIP(hipMemcpyAsync(g->d_desc.p, st->desc.data(), (size_t)nb * sizeof(BlockDesc), hipMemcpyHostToDevice, cs));
+        G_HIP(hipStreamWaitEvent(cs, st->copied, 0));  // the staging thread's copy of this chunk
         G_HIP(hipMemsetAsync(d_nfailed, 0, 64, cs));
         hipLaunchKernelGGL(ginflate_kernel, dim3((nb + kInflThreads - 1) / kInflThreads), dim3(kInflThreads),
-                           (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, cs, g->d_desc.as<BlockDesc>(), nb,
-                           g->d_comp.as<uint8_t>(), d_stream_base, g->d_syms.as<uint16_t>(), d_nfailed, d_failed);
+                           (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, cs, st->d_desc.as<BlockDesc>(), nb,
+                           st->d_comp.as<uint8_t>(), d_stream_base, g->d_syms.as<uint16_t>(), d_nfailed, d_failed);
         G_HIP(hipGetLastError());
         uint32_t n_failed = 0;
         G_HIP(hipMemcpyAsync(&n_failed, d_nfailed, 4, hipMemcpyDeviceToHost, cs));
@@ -819,12 +835,19 @@ extern "C" const char* tec_gbam_ref_name(const tec_gbam* g, int i) {
 extern "C" uint64_t tec_gbam_file_size(const tec_gbam* g) { return g ? g->file_size : 0; }
 
 static void free_buffers(GbamBuffers* g) {
-    for (DBuf* b : {&g->d_comp, &g->d_desc, &g->d_infl, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
+    for (DBuf* b : {&g->d_infl, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
                     &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
                     &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
         b->release();
-    for (auto& s : g->slots)
+    for (auto& s : g->slots) {
         if (s.pinned) (void)hipHostFree(s.pinned);
+        s.pinned = nullptr;
+        s.pinned_cap = 0;
+        s.d_comp.release();
+        s.d_desc.release();
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        s.copied = nullptr;
+    }
 }
 
 void tec_gbam_cache_release(tec_ctx* ctx) {
@@ -840,6 +863,7 @@ extern "C" void tec_gbam_close(tec_gbam* g) {
     if (g->ctx) {
         (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->s_compute);
+        (void)hipStreamSynchronize(g->ctx->s_copy);  // a staged chunk that was never processed may still be copying
     }
     if (g->ctx && !g->ctx->gbam_cache) {
         g->ctx->gbam_cache = new GbamBuffers(static_cast<GbamBuffers&>(*g));  // parked for the next reader

@@ -7,11 +7,12 @@
 // global-memory round trips on its critical path (on gfx9 loads and stores retire in order through one
 // counter, so a load that follows a store waits for that store).  Hence:
 //   * tables are small and 16-bit, in LDS: literal/length 8-bit first level (256 entries), distance
-//     6-bit (64) -- plus 16 spare entries = 672 bytes per lane -> 192 lanes (three waves) per CU in
-//     126 KiB.  (A 9-bit first level -- 1184 bytes, 128 lanes -- decodes a block 10 % faster, but a
-//     launch holds a third fewer blocks: 48 M-record file 0.56 s -> 0.47 s with the 8-bit level);
-//   * the code lengths of a dynamic block are kept as nibbles in the (not yet built) distance-table
-//     area, so that building the tables touches LDS and registers only;
+//     6-bit (64) = 640 bytes per lane -> 256 lanes (four waves, one per SIMD) per CU in exactly the
+//     160 KiB of LDS.  (A 9-bit first level -- 128 lanes -- decodes a block 10 % faster, but a launch
+//     holds half the blocks: 48 M-record file 0.56 s with 128 lanes, 0.47 s with 192, 0.42 s with 256);
+//   * the code lengths of a dynamic block go to the lane's global scratch as they are decoded (sixteen
+//     nibbles per 64-bit store; stores do not stall the lane) and come back in symbol order for the two
+//     passes of the table builder; the distance lengths stay in two registers;
 //   * codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit,
 //     from per-length counts packed in registers; only their symbols live in global scratch;
 //   * base values and extra-bit counts of length / distance symbols are computed arithmetically;
@@ -46,8 +47,8 @@ constexpr int kLitRoot = TEC_GINF_LITROOT;
 constexpr int kDistRoot = 6;
 constexpr uint32_t kLitEntries = 1u << kLitRoot;
 constexpr uint32_t kDistEntries = 1u << kDistRoot;
-constexpr uint32_t kLenArea = kLitEntries;                            // nibble store of the code lengths: 80 entries behind the literal/length table
-constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries + 16u;  // u16 each: 672 bytes
+constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries;  // u16 each: 640 bytes
+constexpr uint32_t kLenWords = 20;                                 // code lengths of a dynamic block: 320 nibbles in 64-bit words (global)
 constexpr uint32_t kLongSymsPerLane = 320;                            // symbols of codes longer than the first level (u16, global)
 constexpr uint32_t kInPad = 16;                                       // readable bytes the caller guarantees behind the input
 
@@ -59,23 +60,39 @@ enum : int { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kB
 // memory; the host instantiation uses plain arrays.
 //   uint32_t tab(uint32_t i) / void set_tab(uint32_t i, uint32_t v)     i < kEntriesPerLane
 //   uint32_t sym(uint32_t i) / void set_sym(uint32_t i, uint32_t v)     i < kLongSymsPerLane
+//   uint64_t lenw(uint32_t k) / void set_lenw(uint32_t k, uint64_t v)   k < kLenWords
 struct HostMem {
     uint16_t t[kEntriesPerLane];
     uint16_t s[kLongSymsPerLane];
+    uint64_t lw[kLenWords];
+    uint64_t lenw(uint32_t k) const { return lw[k]; }
+    void set_lenw(uint32_t k, uint64_t v) { lw[k] = v; }
     uint32_t tab(uint32_t i) const { return t[i]; }
     void set_tab(uint32_t i, uint32_t v) { t[i] = (uint16_t)v; }
     uint32_t sym(uint32_t i) const { return s[i]; }
     void set_sym(uint32_t i, uint32_t v) { s[i] = (uint16_t)v; }
 };
 
-// Code lengths as nibbles in table entries [kLenArea, kLenArea + 80): four per 16-bit entry.
+// The code lengths of a dynamic block, four bits each, are written once in symbol order (sixteen per
+// 64-bit word, to the lane's global scratch: stores do not stall the lane) and read back in symbol
+// order by the two passes of build_tables (twenty dependent loads per pass).
 template <class Mem>
-TEC_HD uint32_t len_get(const Mem& m, uint32_t i) { return (m.tab(kLenArea + (i >> 2)) >> (4u * (i & 3u))) & 15u; }
-template <class Mem>
-TEC_HD void len_set(Mem& m, uint32_t i, uint32_t v) {
-    const uint32_t e = kLenArea + (i >> 2), sh = 4u * (i & 3u);
-    m.set_tab(e, (m.tab(e) & ~(15u << sh)) | (v << sh));
-}
+struct LenWriter {
+    Mem& m;
+    uint64_t acc = 0;
+    uint32_t i = 0;
+    TEC_HD void put(uint32_t v) {
+        acc |= (uint64_t)v << (4u * (i & 15u));
+        if ((i & 15u) == 15u) {
+            m.set_lenw(i >> 4, acc);
+            acc = 0;
+        }
+        ++i;
+    }
+    TEC_HD void finish() {
+        if (i & 15u) m.set_lenw(i >> 4, acc);
+    }
+};
 
 // Counts of codes per length, 12 bits each, five lengths per 64-bit word (lengths 1..15).
 struct Counts {
@@ -296,10 +313,10 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             continue;
         }
         uint32_t hlit = 288, hdist = 32;
+        bool fixed = false;
+        uint64_t dl_lo = 0x5555555555555555ull, dl_hi = 0x5555555555555555ull;  // distance code lengths, 4 bits each (fixed: all 5)
         if (type == 1u) {  // fixed codes (RFC 1951 3.2.6)
-            for (uint32_t i = 0; i < 80u; ++i) m.set_tab(kLenArea + i, 0u);
-            for (uint32_t i = 0; i < 288u; ++i) len_set(m, i, i < 144u ? 8u : (i < 256u ? 9u : (i < 280u ? 7u : 8u)));
-            for (uint32_t i = 0; i < 32u; ++i) len_set(m, 288u + i, 5u);
+            fixed = true;
         } else {  // dynamic codes: the code-length code first (3.2.7)
             br.refill();
             hlit = br.get(5) + 257u;
@@ -321,22 +338,35 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             // its 7-bit table sits in the (not yet built) literal/length area; no code is longer than 7 bits
             if (!build_tables(m, [&](uint32_t i) { return (uint32_t)(cl >> (3u * i)) & 7u; }, 19u, 7u, 0u, 0u, true, &unused))
                 return kBadCodeLengths;
-            for (uint32_t i = 0; i < 80u; ++i) m.set_tab(kLenArea + i, 0u);
-            uint32_t i = 0, prev = 0;
+            dl_lo = dl_hi = 0;
+            LenWriter<Mem> lw{m};
+            uint32_t prev = 0;
+            bool has_eob = false;
             const uint32_t want = hlit + hdist;
-            while (i < want) {
+            auto put = [&](uint32_t v) {
+                if (lw.i >= hlit) {  // the distance code lengths stay in registers (<= 32 x 4 bits)
+                    const uint32_t j = lw.i - hlit;
+                    const uint64_t x = (uint64_t)v << (4u * (j & 15u));
+                    dl_lo |= j < 16u ? x : 0ull;
+                    dl_hi |= j < 16u ? 0ull : x;
+                } else if (lw.i == 256u) {
+                    has_eob = v != 0u;
+                }
+                lw.put(v);
+            };
+            while (lw.i < want) {
                 br.refill();
                 const uint32_t e = m.tab(br.peek(7));
                 if ((e & 15u) == 0u) return kBadCodeLengths;
                 br.drop(e & 15u);
                 const uint32_t s = e >> 4;
                 if (s < 16u) {
-                    len_set(m, i++, s);
+                    put(s);
                     prev = s;
                 } else {
                     uint32_t rep, v = 0;
                     if (s == 16u) {
-                        if (i == 0) return kBadCodeLengths;
+                        if (lw.i == 0) return kBadCodeLengths;
                         v = prev;
                         rep = 3u + br.get(2);
                     } else if (s == 17u) {
@@ -344,25 +374,23 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                     } else {
                         rep = 11u + br.get(7);
                     }
-                    if (i + rep > want) return kBadCodeLengths;
-                    if (v)
-                        for (uint32_t k = 0; k < rep; ++k) len_set(m, i + k, v);
-                    i += rep;
+                    if (lw.i + rep > want) return kBadCodeLengths;
+                    for (uint32_t k = 0; k < rep; ++k) put(v);
                     prev = v;
                 }
             }
+            lw.finish();
             if (br.overrun()) return kInputOverrun;
-            if (len_get(m, 256) == 0u) return kBadCodeLengths;  // no end-of-block code
-        }
-        // the distance code lengths move to registers (<= 32 x 4 bits): their table is built over the nibble store
-        uint64_t dl_lo = 0, dl_hi = 0;
-        for (uint32_t i = 0; i < hdist; ++i) {
-            const uint64_t v = (uint64_t)len_get(m, hlit + i) << (4u * (i & 15u));
-            dl_lo |= i < 16u ? v : 0ull;
-            dl_hi |= i < 16u ? 0ull : v;
+            if (!has_eob) return kBadCodeLengths;  // no end-of-block code
         }
         LongCodes ll, ld;
-        if (!build_tables(m, [&](uint32_t i) { return len_get(m, i); }, hlit, (uint32_t)kLitRoot, 0u, 0u, false, &ll)) return kBadCode;
+        uint64_t lcur = 0;  // both passes of build_tables ask for the lengths in symbol order
+        auto lit_len = [&](uint32_t i) -> uint32_t {
+            if (fixed) return i < 144u ? 8u : (i < 256u ? 9u : (i < 280u ? 7u : 8u));
+            if ((i & 15u) == 0u) lcur = m.lenw(i >> 4);
+            return (uint32_t)(lcur >> (4u * (i & 15u))) & 15u;
+        };
+        if (!build_tables(m, lit_len, hlit, (uint32_t)kLitRoot, 0u, 0u, false, &ll)) return kBadCode;
         if (!build_tables(m, [&](uint32_t i) { return (uint32_t)((i < 16u ? dl_lo : dl_hi) >> (4u * (i & 15u))) & 15u; }, hdist,
                           (uint32_t)kDistRoot, kLitEntries, 288u, false, &ld))
             return kBadCode;

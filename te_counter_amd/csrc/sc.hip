@@ -342,17 +342,36 @@ __global__ void ihead_kernel(uint64_t n, const uint8_t* __restrict__ ghead, cons
 }
 
 // counted = a string is stored / the barcode counter bumps (te_count.py:457-473)
-__global__ void part1_count_kernel(uint64_t n, const uint8_t* __restrict__ ihead, const uint32_t* __restrict__ headidx,
-                                   const int32_t* __restrict__ klass, const uint32_t* __restrict__ bc,
-                                   const uint64_t* __restrict__ ord, uint8_t* counted, uint32_t* cnt,
-                                   unsigned long long* first_seen) {
+// The records are sorted by barcode, so a wave mostly sees one or two barcodes: per distinct barcode of
+// the wave ONE add and ONE min go to memory (37 M atomics on 10 k hot words took 3.5 ms of the 50 M-record run).
+__global__ __launch_bounds__(256) void part1_count_kernel(uint64_t n, const uint8_t* __restrict__ ihead,
+                                                           const uint32_t* __restrict__ headidx, const int32_t* __restrict__ klass,
+                                                           const uint32_t* __restrict__ bc, const uint64_t* __restrict__ ord,
+                                                           uint8_t* counted, uint32_t* cnt, unsigned long long* first_seen) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool c = ihead[i] || klass[i] != klass[headidx[i]];
-    counted[i] = c;
-    if (c) {
-        atomicAdd(&cnt[bc[i]], 1u);
-        atomicMin(&first_seen[bc[i]], (unsigned long long)ord[i]);
+    const bool in = i < n;
+    const bool c = in && (ihead[i] || klass[i] != klass[headidx[i]]);
+    if (in) counted[i] = c;
+    const uint32_t b = c ? bc[i] : 0u;
+    const unsigned long long o = c ? (unsigned long long)ord[i] : ~0ull;
+    const unsigned lane = threadIdx.x & 63u;
+    uint64_t todo = __builtin_amdgcn_ballot_w64(c);
+    while (todo) {  // wave-uniform
+        const int lead = __builtin_ctzll(todo);
+        const uint32_t bl = (uint32_t)__shfl((int)b, lead, 64);
+        const bool mine = c && b == bl;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
+        unsigned long long m = mine ? o : ~0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long other = (unsigned long long)__shfl_xor((long long)m, d, 64);
+            m = other < m ? other : m;
+        }
+        if ((int)lane == lead) {
+            atomicAdd(&cnt[bl], (uint32_t)__builtin_popcountll(mask));
+            atomicMin(&first_seen[bl], m);
+        }
+        todo &= ~mask;
     }
 }
 

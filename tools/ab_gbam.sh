@@ -21,5 +21,5 @@ for rep in range(3):
     t = time.time(); r = m.parse_bampe('/dev/shm/ab.bam'); dt = time.time() - t
     print(sys.argv[1], 'decode_and_count %.3f s' % dt, m.decode_report['blocks'], m.decode_report['seconds'], flush=True)
 PY
-for lib in "$@"; do cp $lib te_counter_amd/libtecount.so && python3 /tmp/ab_one.py $lib; done
+for lib in "$@"; do [ "$lib" -ef te_counter_amd/libtecount.so ] || cp $lib te_counter_amd/libtecount.so; python3 /tmp/ab_one.py $lib; done
 rm -f /dev/shm/ab.bam /dev/shm/ab.tecidx
