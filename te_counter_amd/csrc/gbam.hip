@@ -258,10 +258,15 @@ struct DBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
-struct Staged {  // one chunk of compressed blocks in pinned host memory
-    uint8_t* pinned = nullptr;
-    size_t pinned_cap = 0;
-    size_t bytes = 0;           // compressed bytes to copy
+struct Piece {  // one buffer of the pinned staging ring
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;  // its copy to HBM
+    bool busy = false;
+};
+
+struct Staged {  // one chunk of compressed blocks: staged through the pinned ring into d_comp
+    size_t bytes = 0;           // compressed bytes of the chunk
     uint64_t file_off = 0;      // of byte 0
     std::vector<BlockDesc> desc;
     std::vector<uint64_t> block_off;  // file offset of every block
@@ -287,6 +292,8 @@ struct GbamBuffers {
     DBuf d_flags;
     uint64_t r_cap = 0, u_cap = 0;
     Staged slots[2];
+    Piece pieces[2];
+    int next_piece = 0;
 };
 
 struct tec_gbam : GbamBuffers {
@@ -304,6 +311,7 @@ struct tec_gbam : GbamBuffers {
     // one chunk = one launch of the inflate kernel: 256 lanes x 256 CUs = 65536 blocks fill the chip exactly once
     size_t chunk_bytes = 2047u << 20;
     uint32_t chunk_blocks = 256u * kInflThreads;
+    size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size
     int read_threads = 8;
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
@@ -367,75 +375,117 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         g->mean_block_bytes = nb ? (double)o / nb : 65536.0;
     }
     const uint64_t expect = (uint64_t)(g->mean_block_bytes * 1.06 * max_blocks) + (1u << 20);
-    size_t want = (size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off);
-    // (pinning costs ~0.1 s per GB: a buffer that is a little short is used as it is rather than replaced)
-    if (st->pinned_cap && want + 32 > st->pinned_cap && want < st->pinned_cap + st->pinned_cap / 4) want = st->pinned_cap - 32;
-    double t0 = now_s();
-    if (want + 32 > st->pinned_cap) {
-        if (st->pinned) (void)hipHostFree(st->pinned);
-        st->pinned = nullptr;
-        st->pinned_cap = 0;
-        void* p = nullptr;
-        if (hipHostMalloc(&p, want + 32, hipHostMallocDefault) != hipSuccess) {
-            st->error = "cannot allocate pinned staging memory";
-            return;
-        }
-        st->pinned = static_cast<uint8_t*>(p);
-        st->pinned_cap = want + 32;
+    const size_t cap_bytes = (size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off);
+    hipStream_t cp = g->ctx->s_copy;
+    hipError_t e = st->copied ? hipSuccess : hipEventCreateWithFlags(&st->copied, hipEventDisableTiming);
+    if (e == hipSuccess) e = st->d_comp.reserve(cap_bytes + 64);
+    if (e != hipSuccess) {
+        st->error = std::string("cannot allocate the chunk's buffer on the GPU: ") + hipGetErrorString(e);
+        return;
     }
-    g->t_stage_alloc += now_s() - t0;
-    t0 = now_s();
-    // parallel pread: page cache -> pinned memory
-    {
-        const int nt = want > (32u << 20) ? g->read_threads : 1;
-        std::vector<std::thread> th;
-        std::vector<int> ok(nt, 1);
-        const size_t per = (want + nt - 1) / nt;
-        auto work = [&](int t) {
-            size_t a = (size_t)t * per, b = std::min(want, a + per);
-            while (a < b) {
-                const ssize_t k = pread(g->fd, st->pinned + a, b - a, (off_t)(off + a));
-                if (k <= 0) {
-                    ok[t] = 0;
-                    return;
-                }
-                a += (size_t)k;
-            }
-        };
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-        for (int t = 0; t < nt; ++t)
-            if (!ok[t]) {
-                st->error = "read error on the alignment file";
-                return;
-            }
-    }
-    g->t_stage_read += now_s() - t0;
-    memset(st->pinned + want, 0, 32);
-    size_t o = 0;
+    // The window travels in PIECES through a ring of two small pinned buffers (pinning costs ~0.1 s per GB, a
+    // chunk is 1-2 GB): pread a piece, walk its block headers, send its whole blocks to HBM on the copy stream,
+    // go on with the other buffer.  A block cut by the end of a piece is read again as the start of the next one.
+    size_t o = 0;  // bytes of the chunk that are parsed and on their way
     uint64_t infl = 0;
-    while (st->desc.size() < max_blocks) {
+    bool full = false;
+    while (st->desc.size() < max_blocks && !full && st->error.empty() && !st->last) {
         if (off + o >= limit) {
             st->last = true;
             break;
         }
-        size_t bsize, body_off, body_len;
-        uint32_t isize;
-        if (!tec_bgzf_parse(st->pinned, want, o, &bsize, &body_off, &body_len, &isize)) {
-            if (off + want >= g->file_size && want - o < 18 + 8) {  // nothing but a stub at the very end
-                if (want - o != 0) st->error = "truncated BGZF block at the end of the file";
-                st->last = true;
-            } else if (off + want >= g->file_size || want - o >= 65536 + 64) {
-                st->error = "not a BGZF block (corrupt or not a BAM file)";
-            }
-            break;  // else: the block runs past this window; the next chunk starts with it
+        const size_t win = (size_t)std::min<uint64_t>(g->piece_bytes, g->file_size - (off + o));
+        Piece& pc = g->pieces[g->next_piece];
+        g->next_piece ^= 1;
+        double t0 = now_s();
+        if (pc.busy) {
+            (void)hipEventSynchronize(pc.done);
+            pc.busy = false;
         }
-        if (o + bsize > g->chunk_bytes && !st->desc.empty()) break;
-        st->desc.push_back({(uint32_t)body_off, (uint32_t)body_len, (uint32_t)infl, isize});
-        st->block_off.push_back(off + o);
-        infl += isize;
-        o += bsize;
+        if (win + 32 > pc.cap) {
+            if (pc.p) (void)hipHostFree(pc.p);
+            pc.p = nullptr;
+            pc.cap = 0;
+            const size_t want = (size_t)std::min<uint64_t>(g->piece_bytes, std::max<uint64_t>(win, g->file_size - g->first_data_off)) + 32;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess ||
+                (!pc.done && hipEventCreateWithFlags(&pc.done, hipEventDisableTiming) != hipSuccess)) {
+                st->error = "cannot allocate pinned staging memory";
+                break;
+            }
+            pc.p = static_cast<uint8_t*>(p);
+            pc.cap = want;
+        }
+        g->t_stage_alloc += now_s() - t0;
+        t0 = now_s();
+        {  // parallel pread: page cache -> pinned memory
+            const int nt = win > (32u << 20) ? g->read_threads : 1;
+            std::vector<std::thread> th;
+            std::vector<int> ok(nt, 1);
+            const size_t per = (win + nt - 1) / nt;
+            const uint64_t base = off + o;
+            auto work = [&](int t) {
+                size_t a = (size_t)t * per, b = std::min(win, a + per);
+                while (a < b) {
+                    const ssize_t k = pread(g->fd, pc.p + a, b - a, (off_t)(base + a));
+                    if (k <= 0) {
+                        ok[t] = 0;
+                        return;
+                    }
+                    a += (size_t)k;
+                }
+            };
+            for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto& x : th) x.join();
+            for (int t = 0; t < nt; ++t)
+                if (!ok[t]) st->error = "read error on the alignment file";
+            if (!st->error.empty()) break;
+        }
+        g->t_stage_read += now_s() - t0;
+        memset(pc.p + win, 0, 32);
+        const bool to_eof = off + o + win >= g->file_size;
+        size_t q = 0;  // whole blocks of this piece
+        while (st->desc.size() < max_blocks) {
+            if (off + o + q >= limit) {
+                st->last = true;
+                break;
+            }
+            size_t bsize, body_off, body_len;
+            uint32_t isize;
+            if (!tec_bgzf_parse(pc.p, win, q, &bsize, &body_off, &body_len, &isize)) {
+                if (to_eof && win - q < 18 + 8) {  // nothing but a stub at the very end
+                    if (win - q != 0) st->error = "truncated BGZF block at the end of the file";
+                    st->last = true;
+                } else if (to_eof || win - q >= 65536 + 64) {
+                    st->error = "not a BGZF block (corrupt or not a BAM file)";
+                }
+                break;  // else: the block runs past this piece; the next piece starts with it
+            }
+            if (o + q + bsize > cap_bytes && !st->desc.empty()) {
+                full = true;
+                break;
+            }
+            st->desc.push_back({(uint32_t)(o + body_off), (uint32_t)body_len, (uint32_t)infl, isize});
+            st->block_off.push_back(off + o + q);
+            infl += isize;
+            q += bsize;
+        }
+        if (!st->error.empty()) break;
+        if (q) {
+            e = hipMemcpyAsync(st->d_comp.as<uint8_t>() + o, pc.p, q + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
+            if (e == hipSuccess) e = hipEventRecord(pc.done, cp);
+            if (e != hipSuccess) {
+                st->error = std::string("copy of a staged piece to the GPU failed: ") + hipGetErrorString(e);
+                break;
+            }
+            pc.busy = true;
+            o += q;
+        } else if (!st->last && !full && st->desc.size() < max_blocks) {
+            st->error = "not a BGZF block (corrupt or not a BAM file)";  // a whole piece without one complete block
+            break;
+        }
+        if (off + o >= g->file_size) break;
     }
     st->bytes = o;
     st->inflated = infl;
@@ -443,12 +493,8 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
     st->next_off = off + o;
     if (st->next_off >= g->file_size) st->last = st->at_eof = true;
     if (st->next_off >= limit) st->last = true;
-    if (!st->desc.empty() && st->error.empty()) {  // compressed bytes + block descriptors on their way to HBM
-        hipStream_t cp = g->ctx->s_copy;
-        hipError_t e = st->copied ? hipSuccess : hipEventCreateWithFlags(&st->copied, hipEventDisableTiming);
-        if (e == hipSuccess) e = st->d_comp.reserve(st->bytes + 64);
-        if (e == hipSuccess) e = st->d_desc.reserve(st->desc.size() * sizeof(BlockDesc));
-        if (e == hipSuccess) e = hipMemcpyAsync(st->d_comp.p, st->pinned, st->bytes + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
+    if (!st->desc.empty() && st->error.empty()) {  // the block descriptors follow the compressed bytes
+        e = st->d_desc.reserve(st->desc.size() * sizeof(BlockDesc));
         if (e == hipSuccess) e = hipMemcpyAsync(st->d_desc.p, st->desc.data(), st->desc.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, cp);
         if (e == hipSuccess) e = hipEventRecord(st->copied, cp);
         if (e != hipSuccess) st->error = std::string("copy of a staged chunk to the GPU failed: ") + hipGetErrorString(e);
@@ -574,7 +620,9 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
             std::vector<uint8_t> tmp(65536);
             for (uint32_t b : bad) {
                 const BlockDesc& d = st->desc[b];
-                if (!tec_bgzf_inflate_host(st->pinned + d.in_off, d.in_len, tmp.data(), d.isize))
+                std::vector<uint8_t> body(d.in_len + 16, 0);  // (the pinned ring has moved on: read the block again)
+                if (pread(g->fd, body.data(), d.in_len, (off_t)(st->file_off + d.in_off)) != (ssize_t)d.in_len ||
+                    !tec_bgzf_inflate_host(body.data(), d.in_len, tmp.data(), d.isize))
                     return gfail(g, TEC_EINVAL, "BGZF inflate failed (corrupt block at file offset " + std::to_string(st->block_off[b]) + ")");
                 G_HIP(hipMemcpy(d_stream_base + d.out_off, tmp.data(), d.isize, hipMemcpyHostToDevice));
             }
@@ -780,6 +828,10 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
         const long mb = atol(e);
         if (mb >= 1 && mb <= 3072) g->chunk_bytes = (size_t)mb << 20;
     }
+    if (const char* e = getenv("TEC_GBAM_PIECE_KB")) {  // (tests: several pieces per chunk on small files)
+        const long kb = atol(e);
+        if (kb >= 192 && kb <= (2047l << 10)) g->piece_bytes = (size_t)kb << 10;
+    }
     if (const char* e = getenv("TEC_GBAM_READ_THREADS")) {
         const long nt = atol(e);
         if (nt >= 1 && nt <= 64) g->read_threads = (int)nt;
@@ -839,10 +891,12 @@ static void free_buffers(GbamBuffers* g) {
                     &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
                     &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
         b->release();
+    for (auto& pc : g->pieces) {
+        if (pc.p) (void)hipHostFree(pc.p);
+        if (pc.done) (void)hipEventDestroy(pc.done);
+        pc = Piece();
+    }
     for (auto& s : g->slots) {
-        if (s.pinned) (void)hipHostFree(s.pinned);
-        s.pinned = nullptr;
-        s.pinned_cap = 0;
         s.d_comp.release();
         s.d_desc.release();
         if (s.copied) (void)hipEventDestroy(s.copied);

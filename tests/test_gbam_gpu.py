@@ -48,9 +48,11 @@ def same(a, b):
 
 @pytest.fixture
 def small_chunks(monkeypatch):
-    """Many chunks per file: record tails carried between chunks, a chunk boundary inside a record."""
+    """Many chunks per file, several pieces of the pinned staging ring per chunk: record tails carried between
+    chunks, a chunk boundary inside a record, BGZF blocks cut by the end of a piece."""
     monkeypatch.setenv('TEC_GBAM_CHUNK_MB', '1')
     monkeypatch.setenv('TEC_GBAM_CHUNK_BLOCKS', '37')
+    monkeypatch.setenv('TEC_GBAM_PIECE_KB', '192')
 
 
 def _synthetic(tmp_path, payload, n_units, level=1, sc=False):
