@@ -53,20 +53,25 @@ class BamSource:
         q = queue.Queue(maxsize=prefetch)
         stop = threading.Event()
 
+        def put(item):
+            """False once the consumer has gone (it then never empties the queue: a plain put would block for ever
+            and the consumer's join with it)."""
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def reader():
             try:
                 for b in self._batches(want_tags):
-                    while not stop.is_set():
-                        try:
-                            q.put(b, timeout=0.2)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if not put(b):
                         return
-                q.put(None)
+                put(None)
             except BaseException as e:  # hand decoding errors to the consumer
-                q.put(e)
+                put(e)
 
         t = threading.Thread(target=reader, daemon=True)
         t.start()

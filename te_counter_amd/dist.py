@@ -35,7 +35,8 @@ class World:
         w = cls(rank, size, local)
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+            # TEC_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (the ranks share devices, --device N)
+            backend = backend or os.environ.get('TEC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(local)
                 dist.init_process_group(backend, device_id=torch.device('cuda', local))

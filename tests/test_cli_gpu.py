@@ -142,3 +142,52 @@ def test_se_record_without_cigar_raises_like_pysam_would(tmp_path):
     bam.write_bam(aln, ['chr1'], [ok, nocigar_live, ok])
     with pytest.raises(TypeError):
         cli.main(['-i', aln, '-o', str(tmp_path / 'o2.tsv'), '-g', idx, '-m', 'custom', '--se'])
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _launch(argv, nproc, tmp_path):
+    """bin/te_count under torch.distributed.run; the ranks share GPU 0 (gloo carries the exchanges)."""
+    exe = os.path.join(ROOT, 'bin', 'te_count')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), exe] + argv + ['--device', '0']
+    env = dict(os.environ, TEC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('nproc', [2, 3])
+def test_multi_rank_cli_bulk_and_single_cell(nproc, tmp_path):
+    """One process per rank as the driver launches them: every rank decodes its byte range of the BAM on the GPU,
+    PE mates are paired across the range ends, single-cell cells are dealt over the ranks -- the files rank 0 writes
+    are byte-identical to a one-process run (and, for the golden inputs, to the reference's)."""
+    from te_counter_amd import synth
+    ann = synth.make_annotation('hg38', scale=0.02)
+    idx = str(tmp_path / 'ann.tecidx')
+    ann.flat.save(idx)
+    refs = ann.chrom_names + ['chrUn_1']
+    u = synth.make_units(ann, 150_001, seed=31, paired=True)
+    tid, pos, fl, mq = bam.units_to_records(u, len(refs) - 1, True)
+    pe = str(tmp_path / 'pe.bam')
+    bam.write_bam_arrays(pe, refs, tid[:-1], pos[:-1], fl[:-1], mq[:-1], pair_names=True, payload='illumina')  # odd record count
+    one, many = str(tmp_path / 'one.tsv'), str(tmp_path / 'many.tsv')
+    cli.main(['-i', pe, '-o', one, '-g', idx, '-m', 'custom'])
+    _launch(['-i', pe, '-o', many, '-g', idx, '-m', 'custom'], nproc, tmp_path)
+    assert open(many).read() == open(one).read()
+    # single cell on a golden input: the reference's own bytes
+    g = load_golden('sc_rand22_strand' if nproc == 2 else 'sc_topcells_binding')
+    gidx, aln = _prepare(g, tmp_path)
+    wl = tmp_path / 'wl.txt'
+    wl.write_text(''.join(b + '\n' for b in g['whitelist']))
+    out = str(tmp_path / 'cells.tsv')
+    argv = ['-i', aln, '-o', out, '-g', gidx, '-m', 'custom', '--sc', '--se', '-w', str(wl), '--maxcells', str(g['params']['maxcells'])]
+    if g['params']['strand']:
+        argv.append('--strand')
+    _launch(argv, nproc, tmp_path)
+    assert open(out).read() == g['expected']['tsv']
+    assert open(out.replace('.tsv', '.barcode_freq.tsv')).read() == g['expected']['barcode_freq']
