@@ -29,6 +29,25 @@ TEC_HD uint32_t rd32(const uint8_t* p) {
 }
 TEC_HD uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
+// Up to eight bytes at p as a little-endian word; bytes at or beyond e read as `fill`.  One 8-byte
+// load wherever the record allows it: a lane that walks names and tag strings byte by byte spends
+// its time in dependent one-byte round trips.
+TEC_HD uint64_t word_upto(const uint8_t* p, const uint8_t* e, uint8_t fill) {
+    uint64_t w;
+    if (e - p >= 8) {
+        memcpy(&w, p, 8);
+        return w;
+    }
+    w = 0x0101010101010101ull * fill;
+    for (int k = 0; k < 8 && p + k < e; ++k) w = (w & ~(0xFFull << (8 * k))) | ((uint64_t)p[k] << (8 * k));
+    return w;
+}
+// 0x80 in every byte of w that is zero (exact: no carries between bytes).
+TEC_HD uint64_t zero_bytes(uint64_t w) {
+    const uint64_t m = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((w & m) + m) | w | m);
+}
+
 // Size in bytes of the value of an aux field of type `ty` starting at p (p < e), or 0 if it cannot be
 // told (unknown type, or the value runs past e).
 TEC_HD size_t aux_value_size(char ty, const uint8_t* p, const uint8_t* e) {
@@ -39,9 +58,10 @@ TEC_HD size_t aux_value_size(char ty, const uint8_t* p, const uint8_t* e) {
         case 'i': case 'I': case 'f': sz = 4; break;
         case 'Z': case 'H': {
             const uint8_t* z = p;
-            while (z < e && *z) ++z;
-            if (z >= e) return 0;
-            sz = (size_t)(z - p) + 1;
+            uint64_t hit = 0;
+            while (z < e && !(hit = zero_bytes(word_upto(z, e, 1)))) z += 8;
+            if (!hit) return 0;  // no terminator inside the record
+            sz = (size_t)(z - p) + (size_t)(__builtin_ctzll(hit) >> 3) + 1;
             break;
         }
         case 'B': {
@@ -65,18 +85,26 @@ TEC_HD size_t aux_value_size(char ty, const uint8_t* p, const uint8_t* e) {
 // '_'.join(qname.split('/')[0:-1]) (te_count.py:92) as a 64-bit FNV-1a hash: mate names are only
 // compared for equality.  A name without '/' has the empty key.
 TEC_HD uint64_t mate_key_hash(const uint8_t* q, size_t n) {
+    const uint8_t* e = q + n;
     size_t last = n;
     bool any = false;
-    for (size_t i = 0; i < n; ++i)
-        if (q[i] == '/') {
-            last = i;
+    for (size_t i = 0; i < n; i += 8) {  // the last '/'
+        const uint64_t z = zero_bytes(word_upto(q + i, e, 0) ^ 0x2F2F2F2F2F2F2F2Full);
+        if (z) {
+            last = i + (size_t)((63 - __builtin_clzll(z)) >> 3);
             any = true;
         }
+    }
     uint64_t h = 1469598103934665603ull;
     if (!any) return h;
-    for (size_t i = 0; i < last; ++i) {
-        const uint8_t c = q[i] == '/' ? (uint8_t)'_' : q[i];
-        h = (h ^ c) * 1099511628211ull;
+    for (size_t i = 0; i < last; i += 8) {
+        const uint64_t w = word_upto(q + i, e, 0);
+        const size_t m = last - i < 8 ? last - i : 8;
+        for (size_t b = 0; b < m; ++b) {
+            uint8_t c = (uint8_t)(w >> (8 * b));
+            c = c == '/' ? (uint8_t)'_' : c;
+            h = (h ^ c) * 1099511628211ull;
+        }
     }
     return h;
 }
@@ -173,21 +201,24 @@ TEC_HD uint32_t scan_tags(const uint8_t* p, const uint8_t* e, uint8_t* cb24, uin
         p += sz;
     }
     uint32_t tf = 0;
-    for (int k = 0; k < 24; ++k) cb24[k] = ub24[k] = 0;
+    // the 24-byte fields, zero padded, as three words each (the value's terminating NUL and what follows it are masked off)
+    auto field = [](const uint8_t* v, uint32_t n, uint8_t* out24) {
+        for (uint32_t k = 0; k < 3u; ++k) {
+            uint64_t w = 0;
+            if (v && n <= 24u && 8u * k < n) {
+                w = word_upto(v + 8u * k, v + n, 0);
+            }
+            memcpy(out24 + 8u * k, &w, 8);
+        }
+    };
     const uint8_t* b = cb ? cb : cr;
     const uint32_t nb = cb ? ncb : ncr;
-    if (b) {
-        tf |= 1u;
-        if (nb > 24u) tf |= 4u;
-        else for (uint32_t k = 0; k < nb; ++k) cb24[k] = b[k];
-    }
+    if (b) tf |= nb > 24u ? 5u : 1u;
+    field(b, nb, cb24);
     const uint8_t* u = ub ? ub : ur;
     const uint32_t nu = ub ? nub : nur;
-    if (u) {
-        tf |= 2u;
-        if (nu > 24u) tf |= 8u;
-        else for (uint32_t k = 0; k < nu; ++k) ub24[k] = u[k];
-    }
+    if (u) tf |= nu > 24u ? 10u : 2u;
+    field(u, nu, ub24);
     return tf;
 }
 
