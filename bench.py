@@ -15,7 +15,7 @@ At N = 1 the line also carries what a user of te_count sees, all measured in thi
   cpu_baseline_c_1core      the C restatement, one core
   cpu_baseline_c_allcores   the same, threads over disjoint unit ranges
   pcie_inclusive            pinned host batches -> hipMemcpyAsync -> kernel
-  end_to_end_from_bam       a synthetic BAM file on disk -> measureTE.parse_bampe -> TSV
+  end_to_end_from_bam       a synthetic BAM file on disk -> measureTE.parse_bampe -> TSV (+ a 10x-style BAM -> sc_parse_bamse)
   single_cell               BASELINE config 4 (50 M records, 10 k cells) with an oracle sub-check
   secondary                 BASELINE configs 2 (100 M SE, shuffled and coordinate-sorted) and 5 (3 M names)
 (`--legs headline` skips them.)
@@ -257,6 +257,8 @@ def compact(out):
                           'first_run_s': r['first_run']['decode_and_count'], 'warm_run_s': r['warm_run']['decode_and_count'],
                           'with_index_load_and_tsv_s': r['warm_run']['total'], 'seconds': r['decode']['seconds'] if r.get('decode') else None,
                           'tsv_ok': r['tsv_identical_to_oracle_formatting']}
+        if 'single_cell_from_bam' in e:
+            c['single_cell_from_bam'] = pick(e['single_cell_from_bam'], ('records', 'Mrecords_per_s', 'ok'))
         o['end_to_end_from_bam'] = c
     sc = out.get('single_cell')
     if sc and 'error' not in sc:
@@ -433,6 +435,8 @@ def end_to_end(ann, eng, records):
             out['illumina_host_decoder'] = {'Mrecords_per_s_decode_and_count': h['Mrecords_per_s_decode_and_count'],
                                             'threads': h['threads']}
         bench_e2e.cleanup(r)
+    sc = bench_e2e.run_sc(records // 4, ann)
+    out['single_cell_from_bam'] = {k: sc[k] for k in ('records', 'bam_MB', 'run0_s', 'run1_s', 'Mrecords_per_s', 'cells_with_hits', 'ok')}
     out['value'] = out['illumina']['Mrecords_per_s_decode_and_count']
     out['unit'] = 'Mrecords/s (BAM file -> counts, one GPU, index resident)'
     return out

@@ -146,6 +146,10 @@ def main(argv=None):
 
 
 def entry():
+    # A one-process run needs torch for nothing (it only carries the multi-GPU exchanges) and importing it costs
+    # 2-3 s, more than counting a 100 M-record file: keep it out unless a launcher started several ranks.
+    if int(os.environ.get('WORLD_SIZE', '1') or 1) <= 1:
+        os.environ.setdefault('TEC_NO_TORCH', '1')
     try:
         main()
     except KeyboardInterrupt:

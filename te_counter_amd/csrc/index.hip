@@ -26,6 +26,10 @@
 // edge position.  Whether the reference would have looked at the feature at all (its 10 kb
 // bucket-candidate rule) is decided on the device from left/right, see bulk.hip.
 #include <algorithm>
+#include <chrono>
+#include <memory>
+#include <thread>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -48,6 +52,44 @@ inline bool coverage(int32_t gl, int32_t gr, int64_t* lo, int64_t* hi) {
 
 }  // namespace
 
+// A buffer whose pages are first touched by the threads that fill it (std::vector would zero it serially).
+template <class T>
+struct RawBuf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    explicit RawBuf(size_t n_) : p(new T[n_ ? n_ : 1]), n(n_) {}
+    T* data() { return p.get(); }
+    T* begin() { return p.get(); }
+    T& operator[](size_t i) { return p[i]; }
+    size_t size() const { return n; }
+    void swap(RawBuf& o) {
+        p.swap(o.p);
+        std::swap(n, o.n);
+    }
+};
+
+// Host threads for the build (the per-bin work is independent): TEC_INDEX_THREADS, default min(16, cores).
+static int build_threads() {
+    if (const char* e = getenv("TEC_INDEX_THREADS")) {
+        const int t = atoi(e);
+        if (t >= 1 && t <= 256) return t;
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hc ? hc : 1u));
+}
+// fn(begin, end, t) over T contiguous slices of [0, n)
+template <class F>
+static void parallel_slices(int T, uint64_t n, F fn) {
+    if (T <= 1 || n < 4096) {
+        fn((uint64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T, t); });
+    fn((uint64_t)0, n / T, 0);
+    for (auto& x : th) x.join();
+}
+
 extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id, const int32_t* left,
                                const int32_t* right, const uint32_t* meta, uint32_t n_chrom, uint32_t n_names,
                                int bin_shift) {
@@ -60,6 +102,15 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (bin_shift != 0 && (bin_shift < kMinShift || bin_shift > kMaxShift))
         return tec_fail(ctx, TEC_EINVAL, "tec_index_build: bin_shift %d outside [%d, %d]", bin_shift, kMinShift, kMaxShift);
 
+    // TEC_INDEX_TIMING=1: phase times of the build on stderr
+    const bool timing = getenv("TEC_INDEX_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[tec_index_build] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // pass 1: validate, per-chromosome extent, entry totals for every candidate shift
     std::vector<int64_t> chrom_hi(n_chrom, -1);
     uint64_t entries_at[kMaxShift + 1] = {0};
@@ -80,6 +131,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
         chrom_hi[chrom_id[i]] = std::max(chrom_hi[chrom_id[i]], hi);
         for (int s = kMinShift; s <= kMaxShift; ++s) entries_at[s] += (uint64_t)((hi >> s) - (lo >> s) + 1);
     }
+    mark("pass 1 (validate, extents)");
     auto bins_at = [&](int s) {
         uint64_t b = 0;
         for (uint32_t c = 0; c < n_chrom; ++c)
@@ -121,61 +173,78 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     for (uint32_t i = 0; i < n_names; ++i) ext2int[int2ext[i]] = i;
     const uint32_t name_mask = (1u << TEC_META_NAME_BITS) - 1;
 
+    mark("name order");
     // pass 2: counting sort of (feature, fine bin) pairs
+    const int T = build_threads();
     std::vector<uint32_t> bin_off(n_bins + 1, 0);
-    for (uint64_t i = 0; i < n; ++i) {
-        int64_t lo, hi;
-        if (!coverage(left[i], right[i], &lo, &hi)) continue;
-        const uint32_t base = chrom_base[chrom_id[i]];
-        for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) ++bin_off[base + b + 1];
-    }
-    for (uint64_t b = 0; b < n_bins; ++b) bin_off[b + 1] += bin_off[b];
-    std::vector<tec_entry> entries(n_entries);
-    {
-        std::vector<uint32_t> cursor(bin_off.begin(), bin_off.end() - 1);
-        for (uint64_t i = 0; i < n; ++i) {
+    parallel_slices(T, n, [&](uint64_t i0, uint64_t i1, int) {
+        for (uint64_t i = i0; i < i1; ++i) {
             int64_t lo, hi;
             if (!coverage(left[i], right[i], &lo, &hi)) continue;
             const uint32_t base = chrom_base[chrom_id[i]];
-            const tec_entry e{left[i], right[i], (meta[i] & ~name_mask) | ext2int[meta[i] & name_mask], 0u};
-            for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) entries[cursor[base + b]++] = e;
+            for (int64_t b = lo >> shift; b <= (hi >> shift); ++b) __atomic_fetch_add(&bin_off[base + b + 1], 1u, __ATOMIC_RELAXED);
         }
+    });
+    for (uint64_t b = 0; b < n_bins; ++b) bin_off[b + 1] += bin_off[b];
+    RawBuf<tec_entry> entries(n_entries);
+    {
+        // (the order in which threads fill a bin does not matter: the bin is sorted below by a total order)
+        std::vector<uint32_t> cursor(bin_off.begin(), bin_off.end() - 1);
+        parallel_slices(T, n, [&](uint64_t i0, uint64_t i1, int) {
+            for (uint64_t i = i0; i < i1; ++i) {
+                int64_t lo, hi;
+                if (!coverage(left[i], right[i], &lo, &hi)) continue;
+                const uint32_t base = chrom_base[chrom_id[i]];
+                const tec_entry e{left[i], right[i], (meta[i] & ~name_mask) | ext2int[meta[i] & name_mask], 0u};
+                for (int64_t b = lo >> shift; b <= (hi >> shift); ++b)
+                    entries[__atomic_fetch_add(&cursor[base + b], 1u, __ATOMIC_RELAXED)] = e;
+            }
+        });
     }
-    for (uint64_t b = 0; b < n_bins; ++b) {
-        const uint32_t a = bin_off[b], z = bin_off[b + 1];
-        if (z - a > 1)
-            std::sort(entries.begin() + a, entries.begin() + z, [&](const tec_entry& x, const tec_entry& y) {
-                const uint32_t nx = x.meta & name_mask, ny = y.meta & name_mask;
-                if (nx != ny) return nx < ny;
-                const uint32_t sx = x.meta >> TEC_META_STRAND_SHIFT, sy = y.meta >> TEC_META_STRAND_SHIFT;
-                if (sx != sy) return sx < sy;  // (name, strand) pairs adjacent: single-cell dedupe
-                if (x.left != y.left) return x.left < y.left;
-                if (x.right != y.right) return x.right < y.right;
-                return x.meta < y.meta;
-            });
-    }
+    parallel_slices(T, n_bins, [&](uint64_t b0, uint64_t b1, int) {
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint32_t a = bin_off[b], z = bin_off[b + 1];
+            if (z - a > 1)
+                std::sort(entries.begin() + a, entries.begin() + z, [&](const tec_entry& x, const tec_entry& y) {
+                    const uint32_t nx = x.meta & name_mask, ny = y.meta & name_mask;
+                    if (nx != ny) return nx < ny;
+                    const uint32_t sx = x.meta >> TEC_META_STRAND_SHIFT, sy = y.meta >> TEC_META_STRAND_SHIFT;
+                    if (sx != sy) return sx < sy;  // (name, strand) pairs adjacent: single-cell dedupe
+                    if (x.left != y.left) return x.left < y.left;
+                    if (x.right != y.right) return x.right < y.right;
+                    return x.meta < y.meta;
+                });
+        }
+    });
 
+    mark("counting sort + bin sorts");
     // Exact duplicates inside a bin (the same exon listed once per transcript) change no hit
     // set -- hits are sets of names / (name, strand) pairs and class bits are OR-ed -- drop them.
     {
+        auto same = [](const tec_entry& q, const tec_entry& r) { return q.left == r.left && q.right == r.right && q.meta == r.meta; };
         std::vector<uint32_t> new_off(n_bins + 1, 0);
-        uint64_t w = 0;
-        for (uint64_t b = 0; b < n_bins; ++b) {
-            new_off[b] = (uint32_t)w;
-            for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) {
-                if (i > bin_off[b] && w > new_off[b]) {
-                    const tec_entry& q = entries[w - 1];
-                    if (q.left == entries[i].left && q.right == entries[i].right && q.meta == entries[i].meta) continue;
-                }
-                entries[w++] = entries[i];
+        parallel_slices(T, n_bins, [&](uint64_t b0, uint64_t b1, int) {  // survivors per bin
+            for (uint64_t b = b0; b < b1; ++b) {
+                uint32_t k = 0;
+                for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) k += (i == bin_off[b] || !same(entries[i - 1], entries[i])) ? 1u : 0u;
+                new_off[b + 1] = k;
             }
-        }
-        new_off[n_bins] = (uint32_t)w;
+        });
+        for (uint64_t b = 0; b < n_bins; ++b) new_off[b + 1] += new_off[b];
+        RawBuf<tec_entry> kept(new_off[n_bins]);
+        parallel_slices(T, n_bins, [&](uint64_t b0, uint64_t b1, int) {
+            for (uint64_t b = b0; b < b1; ++b) {
+                uint32_t w = new_off[b];
+                for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i)
+                    if (i == bin_off[b] || !same(entries[i - 1], entries[i])) kept[w++] = entries[i];
+            }
+        });
         bin_off.swap(new_off);
-        entries.resize(w);
+        entries.swap(kept);
     }
     const uint64_t n_entries_kept = entries.size();
 
+    mark("duplicate removal");
     // upload as one blob
     TEC_HIP(ctx, hipSetDevice(ctx->device));
     TEC_HIP(ctx, hipDeviceSynchronize());
@@ -188,7 +257,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const int rec_ne = shift <= 15 && n_bins < (1ull << 26) ? ctx->rec_ne_wanted : 0;
     const size_t rec_words = rec_ne ? 2 + 2 * (size_t)rec_ne : 0;
     const size_t o_rec = align_up(o_cn + n_chrom * sizeof(uint32_t), 256);
-    std::vector<uint32_t> recs((size_t)(n_bins + 1) * rec_words + 4, 0u);  // + one all-zero record (idx.zero_rec)
+    RawBuf<uint32_t> recs((size_t)(n_bins + 1) * rec_words + 4);  // + one all-zero record (idx.zero_rec)
+    for (size_t k = (size_t)n_bins * rec_words; k < recs.size(); ++k) recs[k] = 0u;
     uint64_t n_pieces = 0;
     std::vector<uint32_t> cont;  // 4 words per piece = two {left16 | right16<<16, meta} entries
     if (rec_ne) {
@@ -206,12 +276,30 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     const size_t o_cont = align_up(o_rec + (n_bins + 1) * rec_words * 4 + 16, 256);
     const size_t total = align_up(o_cont + std::max<size_t>(cont.size(), 8) * 4, 256);
     if (rec_ne) {
-        uint64_t piece = 0;
         const int64_t width = (int64_t)1 << shift;
-        uint64_t b = 0;
-        for (uint32_t c = 0; c < n_chrom; ++c)
-            for (uint32_t lb = 0; lb < chrom_nbins[c]; ++lb, ++b) {
+        // continuation pieces are numbered in bin order: each slice first learns how many lie before it
+        std::vector<uint64_t> before(T + 1, 0);
+        auto pieces_of = [&](uint64_t b) {
+            const uint32_t cnt = bin_off[b + 1] - bin_off[b];
+            return cnt > (uint32_t)rec_ne ? (uint64_t)(cnt - rec_ne + 1) / 2 : (uint64_t)0;
+        };
+        const int Tr = n_bins < 4096 ? 1 : T;
+        parallel_slices(Tr, n_bins, [&](uint64_t b0, uint64_t b1, int t) {
+            uint64_t k = 0;
+            for (uint64_t b = b0; b < b1; ++b) k += pieces_of(b);
+            before[t + 1] = k;
+        });
+        for (int t = 0; t < Tr; ++t) before[t + 1] += before[t];
+        parallel_slices(Tr, n_bins, [&](uint64_t b0, uint64_t b1, int t) {
+            uint64_t piece = before[t];
+            // chromosome of the slice's first bin
+            uint32_t c = (uint32_t)(std::upper_bound(chrom_base.begin(), chrom_base.end(), (uint32_t)b0) - chrom_base.begin());
+            c = c ? c - 1 : 0;
+            for (uint64_t b = b0; b < b1; ++b) {
+                while (b >= (uint64_t)chrom_base[c] + chrom_nbins[c]) ++c;  // (chromosomes without bins are skipped)
+                const uint32_t lb = (uint32_t)(b - chrom_base[c]);
                 uint32_t* r = &recs[b * rec_words];
+                for (size_t k = 0; k < rec_words; ++k) r[k] = 0u;
                 const uint32_t a = bin_off[b], cnt = bin_off[b + 1] - a;
                 const int64_t start = (int64_t)lb << shift;
                 r[0] = cnt;
@@ -223,8 +311,9 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
                     w[0] = (uint32_t)l | ((uint32_t)g << 16);
                     w[1] = entries[a + k].meta;
                 }
-                if (cnt > (uint32_t)rec_ne) piece += (cnt - rec_ne + 1) / 2;
+                piece += pieces_of(b);
             }
+        });
     }
     void* blob = nullptr;
     {
@@ -238,6 +327,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
             TEC_HIP(ctx, hipMalloc(&blob, total));
     }
     char* p = static_cast<char*>(blob);
+    mark("bin records + device malloc");
     hipError_t e = hipMemcpy(p + o_off, bin_off.data(), (n_bins + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && n_entries_kept) e = hipMemcpy(p + o_ent, entries.data(), n_entries_kept * sizeof(tec_entry), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p + o_cb, chrom_base.data(), n_chrom * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -247,6 +337,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (e == hipSuccess && !cont.empty()) e = hipMemcpy(p + o_cont, cont.data(), cont.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     unsigned long long* counts = nullptr;
     uint32_t* d_i2e = nullptr;
+    mark("uploads");
     if (e == hipSuccess) e = hipMalloc(&d_i2e, (size_t)n_names * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(d_i2e, int2ext.data(), (size_t)n_names * sizeof(uint32_t), hipMemcpyHostToDevice);
     // + 8: the carry bookkeeping of the packed LDS counters may touch the slot after the last name (bulk.hip)

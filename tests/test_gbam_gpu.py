@@ -80,6 +80,31 @@ def test_every_field_equals_the_host_decoder(eng, tmp_path, payload, level):
     assert rep['blocks'] > 100 and rep['end_token'] == (os.path.getsize(path), 0)
 
 
+@pytest.mark.parametrize('world', [1, 3])
+def test_header_spanning_several_bgzf_blocks(eng, tmp_path, small_chunks, world):
+    """An assembly with thousands of contigs: the BAM header (text + reference table) fills several BGZF blocks
+    and the first record starts in the middle of one; byte ranges whose start falls inside the header."""
+    ann = synth.make_annotation('hg38', scale=0.02)
+    refs = ann.chrom_names + ['chrUn_KI%06dv1_decoy' % i for i in range(9000)]
+    u = synth.make_units(ann, 20_000, seed=8, paired=True)
+    tid, pos, fl, mq = bam.units_to_records(u, len(ann.chrom_names), True)
+    path = str(tmp_path / 'h.bam')
+    bam.write_bam_arrays(path, refs, tid, pos, fl, mq, pair_names=True, payload='illumina')
+    size = os.path.getsize(path)
+    want = host_decode(path)
+    assert len(want['tid']) == 40_000
+    parts = []
+    for r in range(world):
+        rng = bam.byte_range(size, r, world) if world > 1 else None
+        rep, arr = gpu_decode(eng, path, rng)
+        same(arr, host_decode(path, rng))
+        parts.append(arr)
+    same({k: np.concatenate([p[k] for p in parts]) for k in FIELDS}, want)
+    g = GpuBam(eng, path)
+    assert g.reference_names == refs
+    g.close()
+
+
 def test_many_chunks_and_single_cell_tags(eng, tmp_path, small_chunks):
     _, path, arrays = _synthetic(tmp_path, 'illumina', 120_000, sc=True)
     rep, got = gpu_decode(eng, path)

@@ -92,6 +92,41 @@ def run(records, layout='pe', payload='random', decoder='gpu', scale=1.0, reps=2
     return out
 
 
+def run_sc(records, ann, n_cells=2000, maxcells=2000, reps=2):
+    """What `te_count --sc --se -w WL` does on a 10x-style BAM (CB / UB tags): file -> on-GPU decode -> tec_sc_* -> result
+    mapping, checked against the same records submitted as host arrays (tools/bench_sc.py's path)."""
+    import numpy as np
+    from te_counter_amd import bam, synth
+    from te_counter_amd.measure import measureTE
+    arrays, wl, tables = synth.make_sc_arrays(ann, records, n_cells=n_cells, n_whitelist=100_000, seed=77)
+    n = len(arrays['pos'])
+    td = tempfile.mkdtemp(dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    out = {'records': int(n), 'dir': td}
+    try:
+        bam_path, idx_path, wl_path = os.path.join(td, 'sc.bam'), os.path.join(td, 'ann.tecidx'), os.path.join(td, 'wl.txt')
+        bam.write_bam_arrays(bam_path, tables[0], arrays['cls'], arrays['pos'], arrays['flag'], arrays['mapq'], end=arrays['end'] + 2,
+                             cb=arrays['cb24'], ub=arrays['ub24'], payload='illumina')
+        out['bam_MB'] = round(os.path.getsize(bam_path) / 1e6, 1)
+        ann.flat.save(idx_path)
+        with open(wl_path, 'w') as fh:
+            fh.write(''.join(bytes(r).rstrip(b'\0').decode() + '\n' for r in wl))
+        mte = measureTE('bench_e2e', 20)
+        mte.bind_genome(idx_path)
+        mte.load_genome()
+        for rep in range(reps):
+            t = time.time()
+            result = mte.sc_parse_bamse(bam_path, whitelistfilename=wl_path, label='bench', maxcells=maxcells)
+            out['run%d_s' % rep] = round(time.time() - t, 3)
+        out['Mrecords_per_s'] = round(n / out['run%d_s' % (reps - 1)] / 1e6, 2)
+        out['cells_with_hits'] = len(mte.barcodes)
+        out['total_reads'] = int(mte.total_reads)
+        out['ok'] = mte.total_reads == n + 1 and 0 < len(mte.barcodes) <= n_cells and sum(1 for _ in result) == ann.flat.n_names
+        mte._engine.close()
+    finally:
+        cleanup(out)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--records', type=int, default=12_000_000)
