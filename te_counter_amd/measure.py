@@ -53,9 +53,13 @@ class measureTE:
         self.genelist_glb_filename = genelist_glb_filename
 
     def load_genome(self):
-        """te_count.py:31-35: loads the index and derives all_feature_names."""
+        """te_count.py:31-35: loads the index and derives all_feature_names.  Loading the genome that is already
+        resident on the GPU again (sc_parse_bamse does it on every call, like the reference's part 3) is free."""
         assert getattr(self, 'genelist_glb_filename', None) is not None, 'You need to bind the genome first'
         src = self.genelist_glb_filename
+        key = (id(src) if isinstance(src, FlatIndex) else (str(src), os.path.getmtime(src), os.path.getsize(src)), self.bin_shift)
+        if self._engine is not None and getattr(self, '_resident', None) == key:
+            return
         if isinstance(src, FlatIndex):
             self.genome = src
         elif str(src).endswith('.glb'):
@@ -66,6 +70,7 @@ class measureTE:
         if self._engine is None:
             self._engine = Engine(self.device)
         self._engine.upload_index(self.genome, self.bin_shift)
+        self._resident = key
 
     # ------------------------------------------------------------------ bulk
     def _open(self, filename, byte_range=None):
@@ -251,8 +256,7 @@ class measureTE:
         log = log or _NullLog()
         if not os.path.exists(whitelistfilename):
             raise AssertionError(f'{whitelistfilename} -w whitelist file not found')
-        with open(whitelistfilename, 'r') as fh:
-            whitelist = sorted(set(line.strip() for line in fh))  # te_count.py:330-339
+        whitelist, packed_whitelist = _reads.load_whitelist(whitelistfilename)  # te_count.py:330-339
         self.barcodes = {}
         q = self.quality_threshold
         q_int = int(q) if isinstance(q, (int, np.integer)) else None
@@ -277,7 +281,7 @@ class measureTE:
             for t, c in enumerate(cls_of_tid):
                 key_skip[c] = skip[t]
             key_chrom = np.array([self.genome._chrom_lookup.get(k, -1) for k in keys], np.int32)
-            eng.sc_begin(strand, q_int or 0, _reads.pack_whitelist(whitelist), self.BUNDLE_KEYS, key_chrom, key_skip)
+            eng.sc_begin(strand, q_int or 0, packed_whitelist, self.BUNDLE_KEYS, key_chrom, key_skip)
             if on_gpu:
                 report = src.run_sc(q_int, cls_of_tid)
                 self.decode_report = report

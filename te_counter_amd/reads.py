@@ -221,13 +221,73 @@ def pack_whitelist(sorted_barcodes):
     """sorted(set(whitelist lines)) -> uint8[n,24]; the row number is the barcode id
     (te_count.py:338).  Python's str order equals bytewise order of the UTF-8 encoding."""
     n = len(sorted_barcodes)
+    if n == 0:
+        return np.zeros((0, TAG_BYTES), np.uint8)
+    arr = np.array([v.encode('utf-8') for v in sorted_barcodes], dtype='S')
+    return _pack_fixed(arr, sorted_barcodes)
+
+
+def _pack_fixed(arr, names):
+    """numpy 'S' array (one barcode per element) -> uint8[n,24], zero padded."""
+    n, width = len(arr), arr.dtype.itemsize
+    raw = arr.view(np.uint8).reshape(n, width)
+    if width > TAG_BYTES and raw[:, TAG_BYTES:].any():
+        bad = int(np.nonzero(raw[:, TAG_BYTES:].any(axis=1))[0][0])
+        raise ValueError('whitelist barcode %r is longer than %d bytes' % (names[bad], TAG_BYTES))
     out = np.zeros((n, TAG_BYTES), np.uint8)
-    for i, v in enumerate(sorted_barcodes):
-        b = v.encode('utf-8')
-        if len(b) > TAG_BYTES or b'\0' in b:
-            raise ValueError('whitelist barcode %r is longer than %d bytes' % (v, TAG_BYTES))
-        out[i, :len(b)] = np.frombuffer(b, np.uint8)
+    out[:, :min(width, TAG_BYTES)] = raw[:, :TAG_BYTES]
     return out
+
+
+class BarcodeNames:
+    """whitelist id -> barcode string over a sorted numpy 'S' array; strings are made when they are asked for
+    (a run touches a few thousand of the millions of whitelist entries)."""
+
+    def __init__(self, arr):
+        self._arr = arr
+
+    def __len__(self):
+        return len(self._arr)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [b.decode('utf-8') for b in self._arr[i].tolist()]
+        return self._arr[i].decode('utf-8')
+
+    def __iter__(self):
+        return (b.decode('utf-8') for b in self._arr.tolist())
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
+def load_whitelist(path):
+    """The reference's whitelist: set(line.strip() for line in file), sorted (te_count.py:330-339) -> (barcode id ->
+    string sequence, uint8[n,24]).  A 10x v3 whitelist has 6.8 M lines: a file of equal-length lines without stray
+    whitespace (the normal case) is handled as one numpy array; anything else line by line on bytes.
+    (bytes.strip removes ASCII whitespace; barcodes are ASCII.)"""
+    with open(path, 'rb') as fh:
+        data = fh.read()
+    if b'\0' in data:
+        raise ValueError('whitelist file with a NUL byte')
+    arr = None
+    first = data.find(b'\n')
+    if first > 0 and len(data) % (first + 1) == 0:
+        raw = np.frombuffer(data, np.uint8).reshape(-1, first + 1)
+        body = raw[:, :first]
+        if (raw[:, first] == 10).all() and not ((body == 32) | ((body >= 9) & (body <= 13))).any():
+            arr = np.unique(np.ascontiguousarray(body).view('S%d' % first).reshape(-1))
+    if arr is None:
+        lines = data.split(b'\n')
+        if lines and lines[-1] == b'':
+            lines.pop()  # iterating a file yields nothing after the final newline
+        uniq = list(set(map(bytes.strip, lines)))
+        if not uniq:
+            return BarcodeNames(np.zeros(0, 'S1')), np.zeros((0, TAG_BYTES), np.uint8)
+        arr = np.array(uniq, dtype='S')
+        arr.sort()
+    names = BarcodeNames(arr)
+    return names, _pack_fixed(arr, names)
 
 
 def sc_batch_arrays(batch, tid_class):

@@ -84,15 +84,19 @@ def run_parts(eng, world, n_records_local, bundle_keys, maxcells, pad):
     # ---- merge (cells are disjoint over the ranks)
     res = {'total_records': total, 'raw_ids': ids, 'raw_counts': cnt, 'selected': selected,
            'kept_lines': _dist.world_sum(world, out['kept_lines'])}
-    cells = np.concatenate(_dist.all_gather_array(world, out['cells']))
-    hits = np.concatenate(_dist.all_gather_array(world, out['cell_hits']))
-    o = np.argsort(cells, kind='stable')
-    res['cells'], res['cell_hits'] = cells[o], hits[o]
-    cc = np.concatenate(_dist.all_gather_array(world, out['coo_cell']))
-    cn = np.concatenate(_dist.all_gather_array(world, out['coo_name']))
-    cv = np.concatenate(_dist.all_gather_array(world, out['coo_count']))
-    o = np.lexsort((cn, cc))
-    res['coo_cell'], res['coo_name'], res['coo_count'] = cc[o], cn[o], cv[o]
+    if world.size == 1:  # one GPU's triplets come sorted by (cell, name) already
+        res['cells'], res['cell_hits'] = out['cells'], out['cell_hits']
+        res['coo_cell'], res['coo_name'], res['coo_count'] = out['coo_cell'], out['coo_name'], out['coo_count']
+    else:
+        cells = np.concatenate(_dist.all_gather_array(world, out['cells']))
+        hits = np.concatenate(_dist.all_gather_array(world, out['cell_hits']))
+        o = np.argsort(cells, kind='stable')
+        res['cells'], res['cell_hits'] = cells[o], hits[o]
+        cc = np.concatenate(_dist.all_gather_array(world, out['coo_cell']))
+        cn = np.concatenate(_dist.all_gather_array(world, out['coo_name']))
+        cv = np.concatenate(_dist.all_gather_array(world, out['coo_count']))
+        o = np.lexsort((cn, cc))
+        res['coo_cell'], res['coo_name'], res['coo_count'] = cc[o], cn[o], cv[o]
     keys = [k for k in st if k not in ('keys', 'bundles')]
     summed = {k: _dist.world_sum(world, st[k]) for k in keys}
     summed['keys'] = _dist.world_sum(world, st['keys'])
