@@ -55,32 +55,32 @@ class World:
         import torch
         return torch.device('cuda', self.local_rank) if self.backend == 'nccl' else torch.device('cpu')
 
-    def sum_counts(self, counts, stats_vec):
-        """All-reduce (sum) of the per-rank count vector and stats; returns numpy arrays."""
+    def sum_counts(self, counts, stats_vec, reduced=None):
+        """All-reduce (sum) of the per-rank count vector and stats; returns numpy arrays.  counts None: the vector
+        has been reduced on the device already (sum_device_counts) -- `reduced` is handed back and only the stats travel."""
         if self.size == 1:
-            return counts, stats_vec
+            return (reduced if counts is None else counts), stats_vec
         import torch
         import torch.distributed as dist
-        t = torch.from_numpy(np.concatenate([counts.astype(np.int64), np.asarray(stats_vec, np.int64)])).to(self._device())
+        head = np.zeros(0, np.int64) if counts is None else counts.astype(np.int64)
+        t = torch.from_numpy(np.concatenate([head, np.asarray(stats_vec, np.int64)])).to(self._device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         out = t.cpu().numpy()
+        if counts is None:
+            return reduced, out
         return out[:len(counts)].astype(np.uint64), out[len(counts):]
 
-    def sum_device_counts(self, d_counts_ptr, n_names, stats_vec):
-        """In-place RCCL sum all-reduce of a count vector that lives in HBM (libtecount's own buffer,
-        wrapped without a copy), plus the stats; returns (None, stats) -- the caller reads the reduced
-        vector through the engine."""
+    def sum_device_counts(self, d_counts_ptr, n_names):
+        """In-place RCCL sum all-reduce of a count vector that lives in HBM (libtecount's own buffer, wrapped without
+        a copy; the same call bench.py times at N > 1).  The caller reads the reduced vector through the engine."""
         import torch
         import torch.distributed as dist
 
         class _Wrap:
-            __cuda_array_interface__ = {'shape': (n_names,), 'typestr': '<i8', 'data': (d_counts_ptr, False), 'version': 2}
-        t = torch.as_tensor(_Wrap(), device=self._device())
+            __cuda_array_interface__ = {'shape': (int(n_names),), 'typestr': '<i8', 'data': (int(d_counts_ptr), False), 'version': 2}
+        t = torch.as_tensor(_Wrap(), device=torch.device('cuda', self.local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        s = torch.tensor(np.asarray(stats_vec, np.int64), device=self._device())
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
-        return None, s.cpu().numpy()
 
     def gather(self, obj):
         """Every rank's small Python object, in rank order."""

@@ -109,10 +109,16 @@ class measureTE:
                 raise
             failure = e
         world.raise_together(failure)
+        on_device = world.size > 1 and getattr(world, 'backend', None) == 'nccl'
+        if on_device:
+            # RCCL sum all-reduce of the count vector where it lives (libtecount's HBM buffer, in the index's internal
+            # name order, the same on every rank): what bulk_finish then copies out is already the job's total
+            eng.bulk_sync()
+            world.sum_device_counts(eng.bulk_device_buffers()[0], eng.n_names)
         counts, stats, enhancer_only = eng.bulk_finish(raise_enhancer=False)
         keys = ('units', 'assigned', 'lowq', 'badchrom', 'qcfail')
-        if world.size > 1:  # RCCL sum-reduce of the per-GPU count vectors and log counters
-            counts, sv = world.sum_counts(counts, [stats[k] for k in keys] + [int(enhancer_only), n_records])
+        if world.size > 1:  # the log counters (and, without RCCL, the count vector through host memory)
+            counts, sv = world.sum_counts(None if on_device else counts, [stats[k] for k in keys] + [int(enhancer_only), n_records], counts)
             stats = {k: int(v) for k, v in zip(keys, sv)}
             enhancer_only, n_records = bool(sv[5]), int(sv[6])
         if q_int is None and stats['units'] - stats['qcfail'] > 0:
