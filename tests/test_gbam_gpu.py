@@ -131,6 +131,54 @@ def test_byte_ranges_tile_the_file(eng, tmp_path, small_chunks, world):
     dist.check_ranges(reports, size)
 
 
+@pytest.mark.parametrize('chunked,decoys', [(False, False), (True, False), (True, True)])
+def test_long_reads_spanning_many_segments(eng, tmp_path, monkeypatch, chunked, decoys):
+    """Long-read records (up to 400 kb of sequence = 600 KB records) between short ones: whole 64 KiB segments and
+    whole BGZF blocks hold no record start.  decoys: the long records carry, in a B-array tag, three complete
+    plausible BAM records in a row -- exactly what the start-of-range guess looks for.  The whole-file decode is
+    immune (its first record start is known and every later one is reached by the chain); a byte range that
+    begins inside such a tag may guess wrong, and then the range tokens must give it away (dist.check_ranges)."""
+    if chunked:
+        monkeypatch.setenv('TEC_GBAM_CHUNK_BLOCKS', '5')
+        monkeypatch.setenv('TEC_GBAM_PIECE_KB', '192')
+    import random
+    rnd = random.Random(7)
+    refs = [('chr1', 5_000_000), ('chr2', 3_000_000)]
+    payload = bamvec.header(refs)
+    want = []
+    decoy = bamvec.record(1, 1234, 30, 0, 'decoy/1', '50M')
+    for i in range(260):
+        kind = rnd.random()
+        l = 40 if kind < 0.55 else (rnd.randrange(60_000, 90_000) if kind < 0.85 else rnd.randrange(150_000, 400_000))
+        pos = rnd.randrange(0, 2_000_000)
+        aux = bamvec.aux('XD', 'B', list(decoy * 3), 'C') if (decoys and kind >= 0.85) else bamvec.aux('NM', 'i', i)
+        payload += bamvec.record(i % 2, pos, 20 + i % 40, 16 * (i % 2), 'long%d/1' % i, '%dM' % l, aux_bytes=aux)
+        want.append((i % 2, pos, pos + l, 16 * (i % 2), 20 + i % 40))
+    p = str(tmp_path / 'long.bam')
+    bamvec.write_blocks(p, payload, list(range(0xff00, len(payload), 0xff00)), level=1)  # htslib's block size
+    rep, got = gpu_decode(eng, p)
+    assert rep['n_records'] == len(want)
+    for k, col in enumerate(('tid', 'pos', 'end', 'flag', 'mapq')):
+        assert got[col].tolist() == [w[k] for w in want], col
+    same(got, host_decode(p))
+    size = os.path.getsize(p)
+    parts, reports = [], []
+    for r in range(5):
+        rng = bam.byte_range(size, r, 5)
+        rp, arr = gpu_decode(eng, p, rng)
+        same(arr, host_decode(p, rng))  # the two decoders take the same decision, right or wrong
+        parts.append(arr)
+        reports.append(rp)
+    tiled = sum(len(q['tid']) for q in parts) == len(want)
+    if tiled:
+        dist.check_ranges(reports, size)
+        same({k: np.concatenate([q[k] for q in parts]) for k in FIELDS}, got)
+    else:
+        assert decoys
+        with pytest.raises(RuntimeError, match='inconsistent'):
+            dist.check_ranges(reports, size)
+
+
 def test_specification_vectors(eng, tmp_path):
     """The SAM spec's example alignment and the every-CIGAR-op / every-aux-type records, in block layouts
     that cut records (and the size field) across two and more BGZF blocks, with empty blocks."""
