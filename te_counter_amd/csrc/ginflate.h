@@ -409,6 +409,16 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (s < 256u) {
                 if (op >= out_len) return kOutputOverrun;
                 out[op++] = (uint8_t)s;
+                // up to two more literals from the bits already in the buffer (>= 18 after any first code, and a
+                // first-level code has at most kLitRoot bits): lanes in a literal run advance three symbols in the
+                // time a neighbour lane spends on one match (five more, with a refill in between, was slower)
+#pragma unroll
+                for (int extra = 0; extra < 2; ++extra) {
+                    const uint32_t e2 = m.tab(br.peek(kLitRoot));
+                    if ((e2 & 15u) == 0u || (e2 >> 4) >= 256u || op >= out_len) break;
+                    br.drop(e2 & 15u);
+                    out[op++] = (uint8_t)(e2 >> 4);
+                }
                 continue;
             }
             if (s == 256u) break;
@@ -417,9 +427,8 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             // length: symbols 0..7 -> 3..10, then groups of four per extra bit, 28 -> 258
             const uint32_t lx = s < 8u ? 0u : (s == 28u ? 0u : (s - 4u) >> 2);
             uint32_t length = s < 8u ? 3u + s : (s == 28u ? 258u : 3u + ((4u + (s & 3u)) << lx));
-            br.refill();
-            length += br.get(lx);
-            br.refill();
+            length += br.get(lx);  // (the refill at the top left >= 33 bits: a 15-bit code and 5 extra bits fit)
+            br.refill();           // >= 33 bits again: a 15-bit distance code and 13 extra bits fit
             uint32_t d;
             e = m.tab(kLitEntries + br.peek(kDistRoot));
             if (e & 15u) {
@@ -432,7 +441,6 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (d >= 30u) return kBadDistance;
             const uint32_t dx = d < 4u ? 0u : (d - 2u) >> 1;
             uint32_t dist = d < 4u ? 1u + d : 1u + ((2u + (d & 1u)) << dx);
-            br.refill();
             dist += br.get(dx);
             if (dist > op) return kBadDistance;
             if (out_len - op < length) return kOutputOverrun;
@@ -440,23 +448,31 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             uint8_t* q = out + op;
             const uint8_t* p = q - dist;
             op += length;
-            if (dist == 1u) {  // a run of one byte (quality strings): no loads beyond the one byte
-                const uint64_t v = 0x0101010101010101ull * (uint64_t)*p;
-                uint32_t k = 0;
-                for (; k + 8u <= length; k += 8u) memcpy(q + k, &v, 8);
-                for (; k < length; ++k) q[k] = (uint8_t)v;
-            } else if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
-                uint32_t k = 0;
-                for (; k + 8u <= length; k += 8u) {
+            if (out_len - op >= 8u) {
+                // Whole 8-byte groups only: the last group may run up to seven bytes past the match -- into bytes
+                // of this block that are not produced yet and will be overwritten when they are.  (The tail of a
+                // match, byte by byte, was up to fourteen dependent one-byte round trips.)
+                if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
+                    for (uint32_t k = 0; k < length; k += 8u) {
+                        uint64_t v;
+                        memcpy(&v, p + k, 8);
+                        memcpy(q + k, &v, 8);
+                    }
+                } else {  // a pattern of `dist` bytes: one load, replicated in the register, stored in whole periods
                     uint64_t v;
-                    memcpy(&v, p + k, 8);
-                    memcpy(q + k, &v, 8);
+                    memcpy(&v, p, 8);  // (bytes from q on are not written yet: masked off)
+                    const uint32_t bits = 8u * dist;
+                    v &= (1ull << bits) - 1ull;
+                    v |= v << bits;                               // 2 periods (dist <= 4: still inside 64 bits)
+                    v |= dist <= 2u ? v << (2u * bits) : 0ull;    // 4 periods
+                    v |= dist == 1u ? v << 32 : 0ull;             // 8 periods
+                    if (dist == 3u) v |= v << 48;                 // (3: 6 bytes from the line above, the rest here)
+                    const uint32_t g = dist == 1u ? 8u : (8u / dist) * dist;  // 8 8 6 8 5 6 7
+                    for (uint32_t k = 0; k < length; k += g) memcpy(q + k, &v, 8);
                 }
-                if (k < length) {  // the tail: read it whole, then write it
-                    uint64_t v = 0;
-                    for (uint32_t j = 0; k + j < length; ++j) v |= (uint64_t)p[k + j] << (8u * j);
-                    for (uint32_t j = 0; k + j < length; ++j) q[k + j] = (uint8_t)(v >> (8u * j));
-                }
+            } else if (dist == 1u) {  // the last bytes of the block: exact writes
+                const uint8_t c = *p;
+                for (uint32_t k = 0; k < length; ++k) q[k] = c;
             } else {
                 for (uint32_t k = 0; k < length; ++k) q[k] = p[k];
             }
