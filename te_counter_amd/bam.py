@@ -211,7 +211,7 @@ def units_to_records(units, spare_tid, paired):
 
 
 def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair_names=False, cb=None, ub=None,
-                     payload='random', seed=1, threads=0, level=1, reference_length=300000000):
+                     payload='random', seed=1, threads=0, level=1, reference_length=300000000, block_bytes=0xff00):
     """Vectorised BAM writer for large synthetic inputs (numpy + zlib, BGZF blocks of 0xff00 bytes
     compressed on a thread pool).  One fixed-width record per read: a 28-character Illumina-style
     name (mates share it up to '/1' '/2' when pair_names), CIGAR 50M <gap>N 50M (gap = end - pos - 100,
@@ -274,14 +274,14 @@ def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair
     del rec
 
     def pack(off):
-        data = payload_bytes[off:off + 0xff00]
+        data = payload_bytes[off:off + block_bytes]
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
         c = co.compress(data) + co.flush()
         return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(c) + 25) + c +
                 struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data)))
 
     workers = threads or min(16, os.cpu_count() or 1)
-    offs = range(0, len(payload_bytes), 0xff00)
+    offs = range(0, len(payload_bytes), block_bytes)
     with open(path, 'wb') as fh, cf.ThreadPoolExecutor(workers) as ex:
         for blk in ex.map(pack, offs, chunksize=64):
             fh.write(blk)

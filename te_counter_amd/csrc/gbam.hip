@@ -78,7 +78,7 @@ struct DevMem {
     __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
 };
 
-__global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
+__global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(kInflThreads / 256, kInflThreads / 256))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
                                                                 uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed) {
     extern __shared__ uint16_t lds_tab[];
@@ -278,6 +278,11 @@ struct Staged {  // one chunk of compressed blocks: staged through the pinned ri
     // the staging thread also starts the chunk's copy to HBM (copy stream): it overlaps the GPU's work on the chunk before
     DBuf d_comp, d_desc;
     hipEvent_t copied = nullptr;
+    // the chunk's inflate launch (its own scratch and failed-block list: two launches are in flight at a time)
+    DBuf d_syms, d_ctl;
+    hipEvent_t inflate_done = nullptr;
+    bool launched = false;
+    int buf = 0;  // which of the two inflated-stream buffers it writes
 };
 
 }  // namespace
@@ -286,12 +291,15 @@ struct Staged {  // one chunk of compressed blocks: staged through the pinned ri
 // context (allocating and freeing gigabytes of HBM and pinned memory costs more than decoding a small file),
 // the next reader on that context takes them over, tec_destroy frees them.
 struct GbamBuffers {
-    DBuf d_infl, d_syms, d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
+    DBuf d_infl2[2], d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
     DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
     DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
     DBuf d_flags;
     uint64_t r_cap = 0, u_cap = 0;
-    Staged slots[2];
+    Staged slots[3];
+    hipStream_t s_infl2[2] = {nullptr, nullptr};  // one inflate stream per stream buffer: the two launches in flight overlap
+    hipEvent_t buf_free[2] = {nullptr, nullptr};  // the stream buffer's last reader has finished
+    int cur_buf = 0;                      // buffer of the chunk being consumed (the carry sits in front of its stream)
     Piece pieces[2];
     int next_piece = 0;
 };
@@ -310,7 +318,7 @@ struct tec_gbam : GbamBuffers {
     uint32_t hdr_inblock = 0;        // ... and its offset inside that block's inflated bytes
     // one chunk = one launch of the inflate kernel: 256 lanes x 256 CUs = 65536 blocks fill the chip exactly once
     size_t chunk_bytes = 2047u << 20;
-    uint32_t chunk_blocks = 256u * kInflThreads;
+    uint32_t chunk_blocks = 256u * kInflThreads < 65536u ? 256u * kInflThreads : 65536u;  // (stream offsets are 32-bit: <= 4 GiB inflated)
     size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size
     int read_threads = 8;
     // run state
@@ -354,6 +362,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
     st->inflated = 0;
     st->file_off = off;
     st->error.clear();
+    st->launched = false;
     st->last = st->at_eof = false;
     const uint64_t limit = epilogue ? g->file_size : std::min<uint64_t>(g->range_end, g->file_size);
     if (off >= g->file_size) {
@@ -462,8 +471,8 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
                 }
                 break;  // else: the block runs past this piece; the next piece starts with it
             }
-            if (o + q + bsize > cap_bytes && !st->desc.empty()) {
-                full = true;
+            if ((o + q + bsize > cap_bytes || infl + isize > 0xFFFF0000ull - kCarryMax - 65536ull) && !st->desc.empty()) {
+                full = true;  // the chunk's compressed buffer or its 32-bit stream offsets are exhausted
                 break;
             }
             st->desc.push_back({(uint32_t)(o + body_off), (uint32_t)body_len, (uint32_t)infl, isize});
@@ -581,6 +590,42 @@ int pair_and_count(tec_gbam* g, RunState* rs, const RunArgs& a, uint64_t first, 
     return TEC_OK;
 }
 
+// Starts the inflate kernel of a staged chunk on the inflate stream, into stream buffer `buf`.  Two launches are
+// in flight at a time (one workgroup holds a CU's whole LDS; a launch of 65 536 blocks covers half the chip), so that
+// while the host and the row kernels deal with chunk k the chip keeps inflating chunk k + 1.
+int launch_inflate(tec_gbam* g, Staged* st, int buf) {
+    tec_ctx* ctx = g->ctx;
+    st->buf = buf;
+    st->launched = true;
+    const uint32_t nb = (uint32_t)st->desc.size();
+    if (!g->s_infl2[buf]) G_HIP(hipStreamCreateWithFlags(&g->s_infl2[buf], hipStreamNonBlocking));
+    hipStream_t si = g->s_infl2[buf];
+    if (!st->inflate_done) G_HIP(hipEventCreateWithFlags(&st->inflate_done, hipEventDisableTiming));
+    if (g->buf_free[buf]) G_HIP(hipStreamWaitEvent(si, g->buf_free[buf], 0));  // its last reader (rows of chunk k - 2)
+    DBuf& infl = g->d_infl2[buf];
+    if (kCarryMax + st->inflated + 256 > infl.cap) {
+        // (growing copies the carry area: nothing may be in flight on either side)
+        G_HIP(hipStreamSynchronize(ctx->s_compute));
+        G_HIP(hipStreamSynchronize(si));
+        G_HIP(infl.reserve(kCarryMax + st->inflated + 256, true, kCarryMax));  // keep: the carry sits below kCarryMax
+    }
+    const uint32_t waves = (nb + 63u) / 64u;
+    G_HIP(st->d_syms.reserve((size_t)std::max(waves, 1u) * kScratchPerWave));
+    G_HIP(st->d_ctl.reserve(64 + (size_t)std::max(nb, 1u) * 4));
+    if (nb) {
+        uint32_t* d_nfailed = st->d_ctl.as<uint32_t>();
+        G_HIP(hipStreamWaitEvent(si, st->copied, 0));  // the staging thread's copy of this chunk
+        G_HIP(hipMemsetAsync(d_nfailed, 0, 64, si));
+        hipLaunchKernelGGL(ginflate_kernel, dim3((nb + kInflThreads - 1) / kInflThreads), dim3(kInflThreads),
+                           (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, si, st->d_desc.as<BlockDesc>(), nb,
+                           st->d_comp.as<uint8_t>(), infl.as<uint8_t>() + kCarryMax, st->d_syms.as<uint16_t>(), d_nfailed,
+                           d_nfailed + 16);
+        G_HIP(hipGetLastError());
+    }
+    G_HIP(hipEventRecord(st->inflate_done, si));
+    return TEC_OK;
+}
+
 // Inflates, segments, walks and extracts one staged chunk.  limit_one: epilogue -- only the record
 // that starts at stream offset 0 (in the carried bytes) is taken.
 int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool limit_one, ChunkResult* res) {
@@ -594,26 +639,21 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     res->total = total;
     res->tail = total;
     if (total == 0) return TEC_OK;
-    // ---- device buffers
-    G_HIP(g->d_infl.reserve(kCarryMax + st->inflated + 256, true, kCarryMax));  // keep: the carry sits below kCarryMax
-    const uint32_t waves = (nb + 63u) / 64u;
-    G_HIP(g->d_syms.reserve((size_t)std::max(waves, 1u) * kScratchPerWave));
-    G_HIP(g->d_ctl.reserve(64 + (size_t)std::max(nb, 1u) * 4));
-    uint32_t* d_nfailed = g->d_ctl.as<uint32_t>();
+    // ---- the inflated stream (the kernel was started ahead of time for all but the first chunk and the epilogue)
+    if (!st->launched) {
+        int rc = launch_inflate(g, st, g->cur_buf);
+        if (rc) return rc;
+    }
+    g->cur_buf = st->buf;
+    uint32_t* d_nfailed = st->d_ctl.as<uint32_t>();
     uint32_t* d_failed = d_nfailed + 16;
-    uint8_t* d_stream_base = g->d_infl.as<uint8_t>() + kCarryMax;  // inflated bytes of this chunk start here
-    uint8_t* d_stream = d_stream_base - carry;                     // stream offset 0
+    uint8_t* d_stream_base = g->d_infl2[st->buf].as<uint8_t>() + kCarryMax;  // inflated bytes of this chunk start here
+    uint8_t* d_stream = d_stream_base - carry;                               // stream offset 0
     double t0 = now_s();
+    G_HIP(hipEventSynchronize(st->inflate_done));
     if (nb) {
-        G_HIP(hipStreamWaitEvent(cs, st->copied, 0));  // the staging thread's copy of this chunk
-        G_HIP(hipMemsetAsync(d_nfailed, 0, 64, cs));
-        hipLaunchKernelGGL(ginflate_kernel, dim3((nb + kInflThreads - 1) / kInflThreads), dim3(kInflThreads),
-                           (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, cs, st->d_desc.as<BlockDesc>(), nb,
-                           st->d_comp.as<uint8_t>(), d_stream_base, g->d_syms.as<uint16_t>(), d_nfailed, d_failed);
-        G_HIP(hipGetLastError());
         uint32_t n_failed = 0;
-        G_HIP(hipMemcpyAsync(&n_failed, d_nfailed, 4, hipMemcpyDeviceToHost, cs));
-        G_HIP(hipStreamSynchronize(cs));
+        G_HIP(hipMemcpy(&n_failed, d_nfailed, 4, hipMemcpyDeviceToHost));
         if (n_failed) {  // the referee: the host's decoder (and zlib behind it) has the last word
             std::vector<uint32_t> bad(n_failed);
             G_HIP(hipMemcpy(bad.data(), d_failed, (size_t)n_failed * 4, hipMemcpyDeviceToHost));
@@ -838,7 +878,7 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     }
     if (const char* e = getenv("TEC_GBAM_CHUNK_BLOCKS")) {
         const long nb = atol(e);
-        if (nb >= 1 && nb <= 49152) g->chunk_blocks = (uint32_t)nb;
+        if (nb >= 1 && nb <= 65536) g->chunk_blocks = (uint32_t)nb;
     }
     if (g->range_begin == 0) {
         g->first_data_off = 0;
@@ -887,7 +927,7 @@ extern "C" const char* tec_gbam_ref_name(const tec_gbam* g, int i) {
 extern "C" uint64_t tec_gbam_file_size(const tec_gbam* g) { return g ? g->file_size : 0; }
 
 static void free_buffers(GbamBuffers* g) {
-    for (DBuf* b : {&g->d_infl, &g->d_syms, &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
+    for (DBuf* b : {&g->d_infl2[0], &g->d_infl2[1], &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
                     &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
                     &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
         b->release();
@@ -899,8 +939,19 @@ static void free_buffers(GbamBuffers* g) {
     for (auto& s : g->slots) {
         s.d_comp.release();
         s.d_desc.release();
+        s.d_syms.release();
+        s.d_ctl.release();
         if (s.copied) (void)hipEventDestroy(s.copied);
-        s.copied = nullptr;
+        if (s.inflate_done) (void)hipEventDestroy(s.inflate_done);
+        s.copied = s.inflate_done = nullptr;
+    }
+    for (auto& e : g->buf_free) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    for (auto& q : g->s_infl2) {
+        if (q) (void)hipStreamDestroy(q);
+        q = nullptr;
     }
 }
 
@@ -918,6 +969,8 @@ extern "C" void tec_gbam_close(tec_gbam* g) {
         (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->s_compute);
         (void)hipStreamSynchronize(g->ctx->s_copy);  // a staged chunk that was never processed may still be copying
+        for (auto q : g->s_infl2)
+            if (q) (void)hipStreamSynchronize(q);  // ... or inflating
     }
     if (g->ctx && !g->ctx->gbam_cache) {
         g->ctx->gbam_cache = new GbamBuffers(static_cast<GbamBuffers&>(*g));  // parked for the next reader
@@ -946,7 +999,11 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     rs.d_first_noend = flags.as<unsigned long long>();
     rs.d_first_mismatch = rs.d_first_noend + 1;
     rs.d_bad_layout = reinterpret_cast<uint32_t*>(rs.d_first_noend + 2);
-    G_HIP(g->d_infl.reserve(kCarryMax + 256));
+    G_HIP(g->d_infl2[0].reserve(kCarryMax + 256));
+    G_HIP(g->d_infl2[1].reserve(kCarryMax + 256));
+    for (auto& e : g->buf_free)
+        if (!e) G_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g->cur_buf = 0;
     g->deferred = a.deferred;
     g->n_resident = 0;
     g->n_records = 0;
@@ -954,7 +1011,7 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     // ---- producer
     std::mutex mu;
     std::condition_variable cv;
-    int ready[2] = {0, 0};  // 0 free, 1 staged
+    int ready[3] = {0, 0, 0};  // 0 free, 1 staged
     bool stop = false;
     uint64_t next_off = g->first_data_off;
     bool producer_done = false;
@@ -978,7 +1035,7 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             }
             cv.notify_all();
             if (last) break;
-            slot ^= 1;
+            slot = (slot + 1) % 3;
         }
     });
     auto finish_producer = [&] {
@@ -1009,6 +1066,24 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             rc = gfail(g, TEC_EINVAL, st->error);
             break;
         }
+        if (!st->launched) {  // the first chunk
+            rc = launch_inflate(g, st, g->cur_buf);
+            if (rc) break;
+        }
+        const int nslot = (slot + 1) % 3;
+        if (!st->last) {  // the next chunk's inflate starts before this chunk is dealt with: two launches in flight
+            {
+                const double tw = now_s();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready[nslot] == 1; });
+                g->t_stage_wait += now_s() - tw;
+            }
+            Staged* nst = &g->slots[nslot];
+            if (nst->error.empty()) {
+                rc = launch_inflate(g, nst, st->buf ^ 1);
+                if (rc) break;
+            }
+        }
         ChunkResult res;
         rc = process_chunk(g, st, a, &rs, false, &res);
         if (rc) break;
@@ -1030,18 +1105,24 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             rc = gfail(g, TEC_EOVERFLOW, "a BAM record larger than 64 MiB is not supported");
             break;
         }
+        const int nbuf = st->buf ^ 1;  // where the next chunk (or the epilogue) has its stream
         if (new_carry) {
-            uint8_t* base = g->d_infl.as<uint8_t>() + kCarryMax;
-            const uint8_t* src = base - res.carry_in + res.tail;
-            // through a side buffer: source and destination may overlap
-            hipError_t e = g->d_carry.reserve(new_carry);
-            if (e == hipSuccess) e = hipMemcpyAsync(g->d_carry.p, src, new_carry, hipMemcpyDeviceToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(base - new_carry, g->d_carry.p, new_carry, hipMemcpyDeviceToDevice, cs);
+            const uint8_t* src = g->d_infl2[st->buf].as<uint8_t>() + kCarryMax - res.carry_in + res.tail;
+            uint8_t* dst = g->d_infl2[nbuf].as<uint8_t>() + kCarryMax - new_carry;
+            hipError_t e = hipMemcpyAsync(dst, src, new_carry, hipMemcpyDeviceToDevice, cs);
             if (e != hipSuccess) {
                 rc = gfail(g, TEC_EHIP, std::string("carry copy failed: ") + hipGetErrorString(e));
                 break;
             }
         }
+        {
+            hipError_t e = hipEventRecord(g->buf_free[st->buf], cs);  // rows are extracted, the tail has moved on
+            if (e != hipSuccess) {
+                rc = gfail(g, TEC_EHIP, std::string("event record failed: ") + hipGetErrorString(e));
+                break;
+            }
+        }
+        g->cur_buf = nbuf;
         rs.carry_len = new_carry;
         end_off = st->next_off;
         at_eof = st->at_eof;
@@ -1054,7 +1135,7 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             ready[slot] = 0;
         }
         cv.notify_all();
-        slot ^= 1;
+        slot = nslot;
     }
     finish_producer();
     if (rc) {
@@ -1064,7 +1145,7 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     (void)last_res;
 
     // ---- the epilogue: a record that starts in owned bytes and ends beyond the range; the end token
-    Staged* ep = &g->slots[slot ^ 1];
+    Staged* ep = &g->slots[(slot + 1) % 3];
     uint64_t off = end_off;
     bool token_done = false;
     if (rs.carry_len && g->start_known) {
@@ -1091,7 +1172,8 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
                 g->n_records += 1;
                 // where it ends: 4 + block_size from stream offset 0
                 uint32_t bs = 0;
-                G_HIP(hipMemcpy(&bs, g->d_infl.as<uint8_t>() + kCarryMax - carry, 4, hipMemcpyDeviceToHost));
+                G_HIP(hipStreamSynchronize(cs));
+                G_HIP(hipMemcpy(&bs, g->d_infl2[g->cur_buf].as<uint8_t>() + kCarryMax - carry, 4, hipMemcpyDeviceToHost));
                 const uint32_t endpos = 4u + bs;
                 uint64_t tok[2];
                 if (stream_to_token(*ep, carry, endpos, tok)) {

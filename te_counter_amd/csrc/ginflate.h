@@ -44,7 +44,10 @@ namespace tec_ginf {
 #define TEC_GINF_LITROOT 8
 #endif
 constexpr int kLitRoot = TEC_GINF_LITROOT;
-constexpr int kDistRoot = 6;
+#ifndef TEC_GINF_DISTROOT
+#define TEC_GINF_DISTROOT 6
+#endif
+constexpr int kDistRoot = TEC_GINF_DISTROOT;
 constexpr uint32_t kLitEntries = 1u << kLitRoot;
 constexpr uint32_t kDistEntries = 1u << kDistRoot;
 constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries;  // u16 each: 640 bytes
