@@ -223,6 +223,32 @@ def test_corrupt_and_truncated_files(eng, tmp_path):
         GpuBam(eng, bad)
 
 
+@pytest.mark.parametrize('where', [0.1, 0.5, 0.95])
+def test_failure_in_a_later_chunk_leaves_the_engine_usable(eng, tmp_path, small_chunks, where):
+    """Many chunks, two inflate launches in flight: a truncated file / a damaged block somewhere in the middle must
+    surface as an error (or as what zlib makes of it), never hang, and the next file on the same engine -- which
+    takes over the parked buffers -- must decode correctly."""
+    _, good, _ = _synthetic(tmp_path, 'illumina', 60_000)
+    raw = open(good, 'rb').read()
+    bad = str(tmp_path / 'bad.bam')
+    open(bad, 'wb').write(raw[:int(len(raw) * where)])
+    with pytest.raises(IOError):
+        gpu_decode(eng, bad)
+    cut = bytearray(raw)
+    for k in range(40):
+        cut[int(len(raw) * where) + 7 * k] ^= 0xA5  # a burst inside deflate streams / block headers
+    open(bad, 'wb').write(bytes(cut))
+    try:
+        _, got = gpu_decode(eng, bad)
+        same(got, host_decode(bad))
+    except IOError:
+        with pytest.raises(IOError):
+            host_decode(bad)
+    rep, got = gpu_decode(eng, good)
+    assert rep['n_records'] == 120_000
+    same(got, host_decode(good))
+
+
 @pytest.mark.parametrize('paired', [False, True])
 def test_counts_from_a_bam_equal_the_oracle(eng, tmp_path, small_chunks, paired):
     """BAM file -> GPU decode -> count kernel, nothing on the host in between: counts, log counters
