@@ -162,21 +162,30 @@ def main():
             'assigned_frac': round(sstats['assigned'] / max(1, n_units), 4),
         }
         t_legs = time.time()
+        leg_s = {}
+
+        def timed(name, fn, *a):
+            t = time.time()
+            r = fn(*a)
+            leg_s[name] = round(time.time() - t, 1)
+            return r
         if 'pcie' in legs:
-            out['pcie_inclusive'] = host_stream(eng, run.units, n_units, rec_per_unit)
+            out['pcie_inclusive'] = timed('pcie', host_stream, eng, run.units, n_units, rec_per_unit)
         if 'cpu' in legs:
-            out['cpu_baseline'] = cpu_baseline_python(ann, run.units, rec_per_unit, paired, eng)
-            out['cpu_baseline_c_1core'] = cpu_baseline_c(ann, run.units, min(args.cpu_sample, n_units), rec_per_unit, eng)
-            out['cpu_baseline_c_allcores'] = cpu_baseline_c_threads(ann, run.units, n_units, rec_per_unit, counts_one_pass=single)
+            out['cpu_baseline'] = timed('cpu_python', cpu_baseline_python, ann, run.units, rec_per_unit, paired, eng)
+            out['cpu_baseline_c_1core'] = timed('cpu_c_1core', cpu_baseline_c, ann, run.units, min(args.cpu_sample, n_units), rec_per_unit, eng)
+            out['cpu_baseline_c_allcores'] = timed('cpu_c_allcores', lambda: cpu_baseline_c_threads(ann, run.units, n_units, rec_per_unit,
+                                                                                                    counts_one_pass=single))
         run.release()
         if 'e2e' in legs:
-            out['end_to_end_from_bam'] = leg(end_to_end, ann, eng, args.e2e_records)
+            out['end_to_end_from_bam'] = timed('e2e', leg, end_to_end, ann, eng, args.e2e_records)
         if 'sc' in legs:
-            out['single_cell'] = leg(single_cell, ann, eng, args.sc_records)
+            out['single_cell'] = timed('sc', leg, single_cell, ann, eng, args.sc_records)
         if 'secondary' in legs:
-            out['secondary'] = leg(secondary, ann, eng, args)
+            out['secondary'] = timed('secondary', leg, secondary, ann, eng, args)
         if legs:
             out['config']['legs_s'] = round(time.time() - t_legs, 1)
+            out['config']['leg_seconds'] = leg_s
         if args.details:
             with open(args.details, 'w') as fh:
                 json.dump(out, fh, indent=1)

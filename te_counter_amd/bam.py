@@ -238,25 +238,45 @@ def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair
     rec['n_cig'] = 3
     rec['l_seq'] = 100
     rec['ntid'] = rec['npos'] = -1
-    ordinal = (np.arange(n) // 2) if pair_names else np.arange(n)
-    names = np.char.add(np.char.add('A00123:45:HXX:1:', np.char.zfill(ordinal.astype(str), 10)), '/')
-    names = np.char.add(names, np.where(np.arange(n) % 2 == 0, '1', '2')) if pair_names else np.char.add(names, '1')
-    rec['name'] = names.astype('S%d' % name_len)  # NUL padded: 28 characters + NUL
     gap = np.zeros(n, np.int64) if end is None else np.asarray(end, np.int64) - np.asarray(pos, np.int64) - 100
     if (gap < 0).any():
         raise ValueError('end must be >= pos + 100')
     rec['cigar'][:, 0] = (50 << 4) | 0
     rec['cigar'][:, 1] = (gap << 4) | 3
     rec['cigar'][:, 2] = (50 << 4) | 0
-    if payload == 'random':
-        rec['seq'] = rng.integers(0, 256, (n, 50), dtype=np.uint8)
-        rec['qual'] = rng.integers(2, 41, (n, 100), dtype=np.uint8)
-    elif payload == 'illumina':
-        nib = np.array([1, 2, 4, 8], np.uint8)
-        rec['seq'] = (nib[rng.integers(0, 4, (n, 50))] << 4) | nib[rng.integers(0, 4, (n, 50))]
-        rec['qual'] = np.array([2, 12, 23, 37], np.uint8)[rng.choice(4, (n, 100), p=[0.01, 0.04, 0.10, 0.85])]
-    else:
+    if payload not in ('random', 'illumina'):
         raise ValueError(payload)
+    workers = threads or min(16, os.cpu_count() or 1)
+    # names, sequence and quality bytes are made in slabs on the thread pool (numpy releases the GIL inside its
+    # generators and ufuncs): 'A00123:45:HXX:1:<10 digits>/<1|2>' + NUL
+    slab = 1 << 20
+    seeds = np.random.SeedSequence(seed).spawn((n + slab - 1) // slab or 1)
+    prefix = np.frombuffer(b'A00123:45:HXX:1:', np.uint8)
+    seq_lut = np.array([(a << 4) | b for a in (1, 2, 4, 8) for b in (1, 2, 4, 8)], np.uint8)
+    qual_lut = np.repeat(np.array([2, 12, 23, 37], np.uint8), [3, 10, 26, 217])  # ~1 %, 4 %, 10 %, 85 % of 256
+
+    def fill(k):
+        lo, hi = k * slab, min(n, (k + 1) * slab)
+        r = np.random.default_rng(seeds[k])
+        view = rec[lo:hi]
+        m = hi - lo
+        nm = np.zeros((m, name_len), np.uint8)
+        nm[:, :16] = prefix
+        ordinal = (np.arange(lo, hi) // 2) if pair_names else np.arange(lo, hi)
+        for d in range(10):
+            nm[:, 16 + d] = (ordinal // 10 ** (9 - d)) % 10 + 48
+        nm[:, 26] = ord('/')
+        nm[:, 27] = (np.arange(lo, hi) % 2 + 49) if pair_names else 49
+        view['name'] = nm.view('S%d' % name_len).reshape(m)
+        if payload == 'random':
+            view['seq'] = r.integers(0, 256, (m, 50), dtype=np.uint8)
+            view['qual'] = r.integers(2, 41, (m, 100), dtype=np.uint8)
+        else:
+            view['seq'] = seq_lut[r.integers(0, 16, (m, 50), dtype=np.uint8)]
+            view['qual'] = qual_lut[r.integers(0, 256, (m, 100), dtype=np.uint8)]
+
+    with cf.ThreadPoolExecutor(workers) as ex:
+        list(ex.map(fill, range(len(seeds))))
     rec['aux'] = b'NHC\x01HIC\x01ASC\x62nMC\x00'
     for tag, arr, hdr in (('cb', cb, b'CBZ'), ('ub', ub, b'UBZ')):
         if arr is not None:
@@ -280,7 +300,6 @@ def write_bam_arrays(path, reference_names, tid, pos, flag, mapq, end=None, pair
         return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(c) + 25) + c +
                 struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data)))
 
-    workers = threads or min(16, os.cpu_count() or 1)
     offs = range(0, len(payload_bytes), block_bytes)
     with open(path, 'wb') as fh, cf.ThreadPoolExecutor(workers) as ex:
         for blk in ex.map(pack, offs, chunksize=64):
