@@ -47,6 +47,7 @@ constexpr uint32_t kSegShift = 16;
 constexpr uint32_t kSeg = 1u << kSegShift;
 constexpr uint32_t kMaxRecPerSeg = kSeg / 36u + 2u;  // a record is at least 36 bytes with its size field
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+const bool kTrace = getenv("TEC_GBAM_TRACE") != nullptr;  // staging-thread phase times on stderr
 constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one chunk to the next
 #ifndef TEC_GINF_THREADS
 #define TEC_GINF_THREADS 256
@@ -408,8 +409,10 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         g->next_piece ^= 1;
         double t0 = now_s();
         if (pc.busy) {
+            const double tw = now_s();
             (void)hipEventSynchronize(pc.done);
             pc.busy = false;
+            if (kTrace) fprintf(stderr, "[stage] waited %.1f ms for a piece's H2D copy\n", (now_s() - tw) * 1e3);
         }
         if (win + 32 > pc.cap) {
             if (pc.p) (void)hipHostFree(pc.p);
@@ -452,8 +455,10 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             if (!st->error.empty()) break;
         }
         g->t_stage_read += now_s() - t0;
+        if (kTrace) fprintf(stderr, "[stage] pread %zu MB in %.1f ms\n", win >> 20, (now_s() - t0) * 1e3);
         memset(pc.p + win, 0, 32);
         const bool to_eof = off + o + win >= g->file_size;
+        const double t_parse = now_s();
         size_t q = 0;  // whole blocks of this piece
         while (st->desc.size() < max_blocks) {
             if (off + o + q >= limit) {
@@ -482,7 +487,10 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         }
         if (!st->error.empty()) break;
         if (q) {
+            const double t_cp = now_s();
+            if (kTrace) fprintf(stderr, "[stage] header walk %.1f ms\n", (t_cp - t_parse) * 1e3);
             e = hipMemcpyAsync(st->d_comp.as<uint8_t>() + o, pc.p, q + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
+            if (kTrace) fprintf(stderr, "[stage] hipMemcpyAsync call %.1f ms\n", (now_s() - t_cp) * 1e3);
             if (e == hipSuccess) e = hipEventRecord(pc.done, cp);
             if (e != hipSuccess) {
                 st->error = std::string("copy of a staged piece to the GPU failed: ") + hipGetErrorString(e);
@@ -496,6 +504,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         }
         if (off + o >= g->file_size) break;
     }
+    if (kTrace) fprintf(stderr, "[stage] chunk at %llu: %zu bytes, %zu blocks\n", (unsigned long long)off, o, st->desc.size());
     st->bytes = o;
     st->inflated = infl;
     if (!st->desc.empty()) g->mean_block_bytes = (double)o / (double)st->desc.size();
