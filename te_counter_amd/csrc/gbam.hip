@@ -79,7 +79,7 @@ struct DevMem {
     __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
 };
 
-__global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(kInflThreads / 256, kInflThreads / 256))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
+__global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1, (kInflThreads + 255) / 256))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
                                                                 uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed) {
     extern __shared__ uint16_t lds_tab[];
