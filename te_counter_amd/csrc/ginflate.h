@@ -455,7 +455,23 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 // Whole 8-byte groups only: the last group may run up to seven bytes past the match -- into bytes
                 // of this block that are not produced yet and will be overwritten when they are.  (The tail of a
                 // match, byte by byte, was up to fourteen dependent one-byte round trips.)
-                if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
+                if (dist >= 32u) {
+                    // four groups per round trip: on gfx9 a load waits for every older store of the lane, so a
+                    // group-by-group copy is one store + load round trip (microseconds under load) per 8 bytes, and
+                    // the wave waits for its lane with the longest match.  32 source bytes are never bytes the same
+                    // batch writes.
+                    for (uint32_t k = 0; k < length; k += 32u) {
+                        uint64_t v0, v1, v2, v3;
+                        memcpy(&v0, p + k, 8);
+                        memcpy(&v1, p + k + 8, 8);
+                        memcpy(&v2, p + k + 16, 8);
+                        memcpy(&v3, p + k + 24, 8);
+                        memcpy(q + k, &v0, 8);
+                        if (k + 8u < length) memcpy(q + k + 8, &v1, 8);
+                        if (k + 16u < length) memcpy(q + k + 16, &v2, 8);
+                        if (k + 24u < length) memcpy(q + k + 24, &v3, 8);
+                    }
+                } else if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
                     for (uint32_t k = 0; k < length; k += 8u) {
                         uint64_t v;
                         memcpy(&v, p + k, 8);
