@@ -57,8 +57,11 @@ class measureTE:
         resident on the GPU again (sc_parse_bamse does it on every call, like the reference's part 3) is free."""
         assert getattr(self, 'genelist_glb_filename', None) is not None, 'You need to bind the genome first'
         src = self.genelist_glb_filename
-        key = (id(src) if isinstance(src, FlatIndex) else (str(src), os.path.getmtime(src), os.path.getsize(src)), self.bin_shift)
-        if self._engine is not None and getattr(self, '_resident', None) == key:
+        # (a FlatIndex is identified by the object itself -- a reference is kept, ids are recycled -- a file by path, mtime, size)
+        key = (src if isinstance(src, FlatIndex) else (str(src), os.path.getmtime(src), os.path.getsize(src)), self.bin_shift)
+        held = getattr(self, '_resident', None)
+        if self._engine is not None and held is not None and held[1] == key[1] and \
+                (held[0] is key[0] if isinstance(src, FlatIndex) else held[0] == key[0]):
             return
         if isinstance(src, FlatIndex):
             self.genome = src
