@@ -794,6 +794,10 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
         if (rc) return rc;
         G_HIP(hipStreamSynchronize(cs));  // the rows are overwritten by the next chunk
     } else if (a.mode == kModeSC) {
+        if (g->n_records == 0 && st->bytes) {  // the first chunk: records per compressed byte x the bytes of the range
+            const uint64_t range_bytes = std::min<uint64_t>(g->range_end, g->file_size) - std::min<uint64_t>(g->first_data_off, g->file_size);
+            (void)tec_sc_expect_records(ctx, (uint64_t)((double)n_rec / (double)st->bytes * (double)range_bytes * 1.02) + n_rec / 50);
+        }
         int rc = tec_sc_submit_device(ctx, n_rec, ra.chrom, ra.pos, ra.end, ra.flag, ra.mapq, ra.cb, ra.ub, ra.tf);
         if (rc) return rc;
     } else if (a.deferred || a.mode == kModeDump) {

@@ -70,6 +70,7 @@ enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_OR0,
 struct tec_sc_state {
     int stranded = 0, mapq_min = 20;
     uint64_t bundle_keys = 10000000;
+    uint64_t expected_records = 0;  // of the whole input, if the caller can tell (the BAM decoder can): sizes the survivor arrays
     uint32_t n_wl = 0, n_class = 0;
     dvec<uint64_t> wl;          // 3 words per barcode, big-endian packed, ascending
     dvec<uint32_t> wl_table;    // open-addressing hash over wl: rank + 1, 0 = empty
@@ -774,7 +775,12 @@ int sc_ingest(tec_ctx* ctx, tec_sc_state* s, uint64_t n, const int32_t* d_cls, c
     const uint64_t need = s->n_live + add;
     if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
     // survivor arrays: room for sixteen batches like this one (<= 128 M records) at the first allocation, doubling after that
-    const size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);  // at most 6 GB up front
+    // -- or, when the caller has said how many records the whole input holds, for this batch's survivor rate applied to
+    // all of them (+ 8 %): fresh device memory is scrubbed by the driver at ~9 ms per GB, and sixteen batches' worth is
+    // 6 GB for a file that is decoded in one 10 M-record chunk
+    size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);  // at most 6 GB up front
+    if (s->expected_records > s->n_seen && s->n_live == 0)
+        floor = (size_t)std::min<uint64_t>((uint64_t)((double)add / (double)n * (double)s->expected_records * 1.08) + 4096, 0xFFFFFFF0ull);
     SC_HIP(s->bcid.reserve(need, true, s->n_live, floor));
     SC_HIP(s->u0.reserve(need, true, s->n_live, floor));
     SC_HIP(s->u1.reserve(need, true, s->n_live, floor));
@@ -838,6 +844,12 @@ extern "C" int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_c
     if (n >= 0x7FFFFFFFull) return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit_device: batch too large");
     SC_HIP(hipSetDevice(ctx->device));
     return sc_ingest(ctx, s, n, d_cls, d_pos, d_end, d_flag, d_mapq, d_cb24, d_ub24, d_tagflags);
+}
+
+int tec_sc_expect_records(tec_ctx* ctx, uint64_t n_records) {
+    if (!ctx || !ctx->sc) return TEC_ESTATE;
+    ctx->sc->expected_records = n_records;
+    return TEC_OK;
 }
 
 namespace {

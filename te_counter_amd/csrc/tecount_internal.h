@@ -131,6 +131,8 @@ void tec_spill_release(tec_ctx* ctx);
 // sc.hip
 void tec_sc_release(tec_ctx* ctx);
 // gbam.hip
+// (sc.hip) how many records the whole input is expected to hold: sizes the survivor arrays at the first batch
+int tec_sc_expect_records(tec_ctx* ctx, uint64_t n_records);
 void tec_gbam_cache_release(tec_ctx* ctx);
 // bamio.hip: BGZF helpers shared with gbam.hip
 size_t tec_bgzf_find_block(const uint8_t* m, size_t len, size_t from);
