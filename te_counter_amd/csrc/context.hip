@@ -1,4 +1,6 @@
 // Context lifetime, error reporting and pinned host memory of libtecount.so.
+#include <cstdlib>
+
 #include "tecount_internal.h"
 
 static thread_local std::string g_create_err;
@@ -23,6 +25,9 @@ extern "C" const char* tec_last_error(const tec_ctx* ctx) { return ctx ? ctx->er
 extern "C" int tec_create(int device_id, tec_ctx** out) {
     if (!out) return tec_fail(nullptr, TEC_EINVAL, "tec_create: out is NULL");
     *out = nullptr;
+    // two inflate launches of the BAM decoder run side by side on two streams: with the default of four hardware queues
+    // per process two of this library's streams may share one (effective only if HIP is not initialised yet)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)

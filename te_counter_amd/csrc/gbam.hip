@@ -6,7 +6,7 @@
 // chunk.  Everything else runs on the MI355X:
 //
 //   ginflate_kernel     one lane inflates one BGZF block (ginflate.h: 16-bit Huffman tables in LDS,
-//                       640 B per lane -> 256 lanes per CU); a block the kernel refuses is redone by
+//                       320 B per lane -> 512 lanes per CU); a block the kernel refuses is redone by
 //                       the host's referee decoder (inflate_fast.h, then zlib) and patched in
 //   seg_guess_kernel    the inflated stream is cut into 64 KiB segments; one wave per segment looks for
 //                       the first offset at which a chain of BAM records plausibly starts (bamscan.h)
@@ -50,7 +50,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 const bool kTrace = getenv("TEC_GBAM_TRACE") != nullptr;  // staging-thread phase times on stderr
 constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one chunk to the next
 #ifndef TEC_GINF_THREADS
-#define TEC_GINF_THREADS 256
+#define TEC_GINF_THREADS 512
 #endif
 constexpr size_t kScratchPerWave = 64u * (tec_ginf::kLongSymsPerLane * 2u + tec_ginf::kLenWords * 8u);  // global scratch of the inflate kernel
 constexpr int kInflThreads = TEC_GINF_THREADS;        // lanes per workgroup of the inflate kernel = lanes per CU (LDS bound)
@@ -64,7 +64,7 @@ struct BlockDesc {
 };
 
 // ---- per-lane memory of the inflate kernel: tables in LDS, lane-interleaved (entry i of lane L at
-// u16 index i * 256 + L: same-i accesses of a wave are consecutive, random-i accesses always land
+// u16 index i * 512 + L: same-i accesses of a wave are consecutive, random-i accesses always land
 // in the lane pair's own bank); the symbols of long codes and the code lengths of the block being
 // set up in global memory, interleaved per wave
 struct DevMem {
@@ -317,7 +317,7 @@ struct tec_gbam : GbamBuffers {
     uint64_t first_data_off = 0;     // file offset of the first BGZF block this reader stages
     uint64_t hdr_block_off = 0;      // range 0: block that holds the first record ...
     uint32_t hdr_inblock = 0;        // ... and its offset inside that block's inflated bytes
-    // one chunk = one launch of the inflate kernel: 256 lanes x 256 CUs = 65536 blocks fill the chip exactly once
+    // one chunk = one launch of the inflate kernel: 65536 blocks = 128 workgroups of 512 lanes; two launches in flight fill the chip
     size_t chunk_bytes = 2047u << 20;
     uint32_t chunk_blocks = 256u * kInflThreads < 65536u ? 256u * kInflThreads : 65536u;  // (stream offsets are 32-bit: <= 4 GiB inflated)
     size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size

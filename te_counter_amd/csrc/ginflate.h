@@ -6,10 +6,11 @@
 // the number of lanes per CU is table memory, and what limits a lane's speed is the number of
 // global-memory round trips on its critical path (on gfx9 loads and stores retire in order through one
 // counter, so a load that follows a store waits for that store).  Hence:
-//   * tables are small and 16-bit, in LDS: literal/length 8-bit first level (256 entries), distance
-//     6-bit (64) = 640 bytes per lane -> 256 lanes (four waves, one per SIMD) per CU in exactly the
-//     160 KiB of LDS.  (A 9-bit first level -- 128 lanes -- decodes a block 10 % faster, but a launch
-//     holds half the blocks: 48 M-record file 0.56 s with 128 lanes, 0.47 s with 192, 0.42 s with 256);
+//   * tables are small and 16-bit, in LDS: literal/length 7-bit first level (128 entries), distance
+//     5-bit (32) = 320 bytes per lane -> 512 lanes (eight waves, two per SIMD) per CU in exactly the
+//     160 KiB of LDS; the second wave of a SIMD issues while the first waits for memory.  Measured
+//     ladder (48 M-record file): 9-bit level, 128 lanes 0.56 s; 8-bit, 192 lanes 0.47 s; 8-bit, 256
+//     lanes 0.42 s -- and, once two launches overlap, 0.258 s against 0.228 s for this layout;
 //   * the code lengths of a dynamic block go to the lane's global scratch as they are decoded (sixteen
 //     nibbles per 64-bit store; stores do not stall the lane) and come back in symbol order for the two
 //     passes of the table builder; the distance lengths stay in two registers;
@@ -41,11 +42,11 @@
 namespace tec_ginf {
 
 #ifndef TEC_GINF_LITROOT
-#define TEC_GINF_LITROOT 8
+#define TEC_GINF_LITROOT 7
 #endif
 constexpr int kLitRoot = TEC_GINF_LITROOT;
 #ifndef TEC_GINF_DISTROOT
-#define TEC_GINF_DISTROOT 6
+#define TEC_GINF_DISTROOT 5
 #endif
 constexpr int kDistRoot = TEC_GINF_DISTROOT;
 constexpr uint32_t kLitEntries = 1u << kLitRoot;
