@@ -301,7 +301,7 @@ struct GbamBuffers {
     hipStream_t s_infl2[2] = {nullptr, nullptr};  // one inflate stream per stream buffer: the two launches in flight overlap
     hipEvent_t buf_free[2] = {nullptr, nullptr};  // the stream buffer's last reader has finished
     int cur_buf = 0;                      // buffer of the chunk being consumed (the carry sits in front of its stream)
-    Piece pieces[2];
+    Piece pieces[3];  // one being walked / copied, one being read, one whose copy to HBM drains
     int next_piece = 0;
 };
 
@@ -394,26 +394,30 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         return;
     }
     // The window travels in PIECES through a ring of two small pinned buffers (pinning costs ~0.1 s per GB, a
-    // chunk is 1-2 GB): pread a piece, walk its block headers, send its whole blocks to HBM on the copy stream,
-    // go on with the other buffer.  A block cut by the end of a piece is read again as the start of the next one.
-    size_t o = 0;  // bytes of the chunk that are parsed and on their way
-    uint64_t infl = 0;
-    bool full = false;
-    while (st->desc.size() < max_blocks && !full && st->error.empty() && !st->last) {
-        if (off + o >= limit) {
-            st->last = true;
-            break;
-        }
-        const size_t win = (size_t)std::min<uint64_t>(g->piece_bytes, g->file_size - (off + o));
+    // chunk is 1-2 GB): pread a piece, walk its block headers, send its whole blocks to HBM on the copy stream.
+    // While a piece is walked (a pointer chase through cold cache lines: 3 ms per 256 MB) the reader threads already
+    // fill the other buffer: a block cut by the end of a piece starts within its last 64 KiB, so the next piece is
+    // read from 64 KiB before that end and the walk goes on at whatever offset in it the next block turns out to have.
+    constexpr size_t kOverlap = 65536 + 64;
+    struct ReadOp {
+        Piece* pc = nullptr;
+        uint64_t base = 0;  // file offset of byte 0 of the buffer
+        size_t win = 0;
+        std::vector<std::thread> th;
+        std::vector<int> ok;
+        bool active = false;
+        double t0 = 0;
+    };
+    auto begin_read = [&](ReadOp& r, uint64_t base) -> bool {
         Piece& pc = g->pieces[g->next_piece];
-        g->next_piece ^= 1;
+        g->next_piece = (g->next_piece + 1) % 3;
         double t0 = now_s();
         if (pc.busy) {
-            const double tw = now_s();
             (void)hipEventSynchronize(pc.done);
             pc.busy = false;
-            if (kTrace) fprintf(stderr, "[stage] waited %.1f ms for a piece's H2D copy\n", (now_s() - tw) * 1e3);
+            if (kTrace) fprintf(stderr, "[stage] waited %.1f ms for a piece's H2D copy\n", (now_s() - t0) * 1e3);
         }
+        const size_t win = (size_t)std::min<uint64_t>(g->piece_bytes, g->file_size - base);
         if (win + 32 > pc.cap) {
             if (pc.p) (void)hipHostFree(pc.p);
             pc.p = nullptr;
@@ -423,41 +427,67 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess ||
                 (!pc.done && hipEventCreateWithFlags(&pc.done, hipEventDisableTiming) != hipSuccess)) {
                 st->error = "cannot allocate pinned staging memory";
-                break;
+                return false;
             }
             pc.p = static_cast<uint8_t*>(p);
             pc.cap = want;
         }
         g->t_stage_alloc += now_s() - t0;
-        t0 = now_s();
-        {  // parallel pread: page cache -> pinned memory
-            const int nt = win > (32u << 20) ? g->read_threads : 1;
-            std::vector<std::thread> th;
-            std::vector<int> ok(nt, 1);
-            const size_t per = (win + nt - 1) / nt;
-            const uint64_t base = off + o;
-            auto work = [&](int t) {
-                size_t a = (size_t)t * per, b = std::min(win, a + per);
-                while (a < b) {
-                    const ssize_t k = pread(g->fd, pc.p + a, b - a, (off_t)(base + a));
+        r.pc = &pc;
+        r.base = base;
+        r.win = win;
+        r.t0 = now_s();
+        const int nt = win > (32u << 20) ? g->read_threads : 1;
+        r.ok.assign(nt, 1);
+        r.th.clear();
+        const size_t per = (win + nt - 1) / nt;
+        uint8_t* dst = pc.p;
+        const int fd = g->fd;
+        for (int t = 0; t < nt; ++t) {
+            int* okp = &r.ok[t];
+            r.th.emplace_back([=] {  // parallel pread: page cache -> pinned memory
+                size_t a = (size_t)t * per, bnd = std::min(win, a + per);
+                while (a < bnd) {
+                    const ssize_t k = pread(fd, dst + a, bnd - a, (off_t)(base + a));
                     if (k <= 0) {
-                        ok[t] = 0;
+                        *okp = 0;
                         return;
                     }
                     a += (size_t)k;
                 }
-            };
-            for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-            work(0);
-            for (auto& x : th) x.join();
-            for (int t = 0; t < nt; ++t)
-                if (!ok[t]) st->error = "read error on the alignment file";
-            if (!st->error.empty()) break;
+            });
         }
-        g->t_stage_read += now_s() - t0;
-        if (kTrace) fprintf(stderr, "[stage] pread %zu MB in %.1f ms\n", win >> 20, (now_s() - t0) * 1e3);
-        memset(pc.p + win, 0, 32);
-        const bool to_eof = off + o + win >= g->file_size;
+        r.active = true;
+        return true;
+    };
+    auto end_read = [&](ReadOp& r, bool wanted) {
+        for (auto& x : r.th) x.join();
+        r.th.clear();
+        r.active = false;
+        if (!wanted) return;
+        for (int v : r.ok)
+            if (!v) st->error = "read error on the alignment file";
+        memset(r.pc->p + r.win, 0, 32);
+        g->t_stage_read += now_s() - r.t0;
+        if (kTrace) fprintf(stderr, "[stage] pread %zu MB, ready %.1f ms after it was asked for\n", r.win >> 20, (now_s() - r.t0) * 1e3);
+    };
+    size_t o = 0;  // bytes of the chunk that are parsed and on their way
+    uint64_t infl = 0;
+    bool full = false;
+    ReadOp cur, nxt;
+    if (off >= limit) st->last = true;
+    else if (!begin_read(cur, off)) cur.active = false;
+    while (cur.active) {
+        end_read(cur, true);
+        if (!st->error.empty()) break;
+        const size_t delta = (size_t)(off + o - cur.base);  // the first unparsed block inside this buffer
+        const uint8_t* pb = cur.pc->p + delta;
+        const size_t win = cur.win - delta;
+        const bool to_eof = cur.base + cur.win >= g->file_size;
+        // read ahead while walking -- unless this piece very likely completes the chunk
+        if (!to_eof && o + win + kOverlap < cap_bytes && cur.base + cur.win < limit + kOverlap) {
+            if (!begin_read(nxt, cur.base + cur.win - kOverlap)) break;
+        }
         const double t_parse = now_s();
         size_t q = 0;  // whole blocks of this piece
         while (st->desc.size() < max_blocks) {
@@ -467,14 +497,14 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             }
             size_t bsize, body_off, body_len;
             uint32_t isize;
-            if (!tec_bgzf_parse(pc.p, win, q, &bsize, &body_off, &body_len, &isize)) {
+            if (!tec_bgzf_parse(pb, win, q, &bsize, &body_off, &body_len, &isize)) {
                 if (to_eof && win - q < 18 + 8) {  // nothing but a stub at the very end
                     if (win - q != 0) st->error = "truncated BGZF block at the end of the file";
                     st->last = true;
                 } else if (to_eof || win - q >= 65536 + 64) {
                     st->error = "not a BGZF block (corrupt or not a BAM file)";
                 }
-                break;  // else: the block runs past this piece; the next piece starts with it
+                break;  // else: the block runs past this piece; the next piece holds it whole
             }
             if ((o + q + bsize > cap_bytes || infl + isize > 0xFFFF0000ull - kCarryMax - 65536ull) && !st->desc.empty()) {
                 full = true;  // the chunk's compressed buffer or its 32-bit stream offsets are exhausted
@@ -485,25 +515,33 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             infl += isize;
             q += bsize;
         }
+        if (kTrace) fprintf(stderr, "[stage] header walk %.1f ms\n", (now_s() - t_parse) * 1e3);
         if (!st->error.empty()) break;
         if (q) {
-            const double t_cp = now_s();
-            if (kTrace) fprintf(stderr, "[stage] header walk %.1f ms\n", (t_cp - t_parse) * 1e3);
-            e = hipMemcpyAsync(st->d_comp.as<uint8_t>() + o, pc.p, q + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
-            if (kTrace) fprintf(stderr, "[stage] hipMemcpyAsync call %.1f ms\n", (now_s() - t_cp) * 1e3);
-            if (e == hipSuccess) e = hipEventRecord(pc.done, cp);
+            e = hipMemcpyAsync(st->d_comp.as<uint8_t>() + o, pb, q + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
+            if (e == hipSuccess) e = hipEventRecord(cur.pc->done, cp);
             if (e != hipSuccess) {
                 st->error = std::string("copy of a staged piece to the GPU failed: ") + hipGetErrorString(e);
                 break;
             }
-            pc.busy = true;
+            cur.pc->busy = true;
             o += q;
         } else if (!st->last && !full && st->desc.size() < max_blocks) {
             st->error = "not a BGZF block (corrupt or not a BAM file)";  // a whole piece without one complete block
             break;
         }
-        if (off + o >= g->file_size) break;
+        if (st->desc.size() >= max_blocks || full || st->last || off + o >= g->file_size) break;
+        if (off + o >= limit) {
+            st->last = true;
+            break;
+        }
+        if (nxt.active && (off + o < nxt.base || off + o > nxt.base + kOverlap)) end_read(nxt, false);  // (cannot happen: read again)
+        if (!nxt.active && !begin_read(nxt, off + o)) break;
+        cur = std::move(nxt);
+        nxt = ReadOp();
     }
+    if (cur.active) end_read(cur, false);
+    if (nxt.active) end_read(nxt, false);
     if (kTrace) fprintf(stderr, "[stage] chunk at %llu: %zu bytes, %zu blocks\n", (unsigned long long)off, o, st->desc.size());
     st->bytes = o;
     st->inflated = infl;
