@@ -2,8 +2,9 @@
 //
 // Replaces pysam.AlignmentFile(filename) / next(sam) and the per-record attribute reads of the
 // reference's loops (te_count/te_count.py:65,78-98 / 190,203-214 / 351,393-438) for BGZF-compressed
-// BAM input.  The host only moves COMPRESSED bytes: pread into pinned memory, one hipMemcpyAsync per
-// chunk.  Everything else runs on the MI355X:
+// BAM input.  The host only moves COMPRESSED bytes: a staging thread preads the file in 256 MB pieces
+// into a ring of pinned buffers, walks the BGZF headers and sends the blocks to HBM on the copy stream
+// (stage_chunk).  Everything else runs on the MI355X:
 //
 //   ginflate_kernel     one lane inflates one BGZF block (ginflate.h: 16-bit Huffman tables in LDS,
 //                       320 B per lane -> 512 lanes per CU); a block the kernel refuses is redone by
@@ -21,6 +22,10 @@
 //   pair_kernel         PE: records (2k, 2k+1) -> counting units (te_count.py:78-98)
 // and the units go straight to the count kernel (tec_bulk_submit_device) or the single-cell ingest
 // (tec_sc_submit_device) without ever visiting host memory.
+//
+// Pipeline (run_decode): a chunk is <= 65 536 blocks (32-bit stream offsets).  Chunk k + 1's inflate is launched
+// -- on its own stream, into the other of two stream buffers -- before chunk k is consumed, so two launches share
+// the chip while the host steps and row kernels of chunk k run; the staging thread is a chunk or two ahead.
 //
 // Multi-GPU: a reader owns a byte range of the file (include/tecount.h, tec_bam_open_range has the
 // rules); the first record of a range that does not start at 0 is a guess that the caller verifies
