@@ -901,7 +901,10 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
     hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->bcid.p, s->s_bcid.p);
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u0.p, s->s_u0.p);
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u1.p, s->s_u1.p);
-    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u2.p, s->s_u2.p);
+    if (masks[0])  // (UMIs of at most 16 bytes leave the third word zero everywhere: nothing to gather)
+        hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u2.p, s->s_u2.p);
+    else
+        SC_HIP(hipMemsetAsync(s->s_u2.p, 0, N * sizeof(uint64_t), st));
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->rec.p, s->s_rec.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->klass.p, s->s_klass.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->left.p, s->s_left.p);
