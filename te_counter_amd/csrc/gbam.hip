@@ -398,7 +398,7 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         st->error = std::string("cannot allocate the chunk's buffer on the GPU: ") + hipGetErrorString(e);
         return;
     }
-    // The window travels in PIECES through a ring of two small pinned buffers (pinning costs ~0.1 s per GB, a
+    // The window travels in PIECES through a ring of three small pinned buffers (pinning costs ~0.1 s per GB, a
     // chunk is 1-2 GB): pread a piece, walk its block headers, send its whole blocks to HBM on the copy stream.
     // While a piece is walked (a pointer chase through cold cache lines: 3 ms per 256 MB) the reader threads already
     // fill the other buffer: a block cut by the end of a piece starts within its last 64 KiB, so the next piece is
