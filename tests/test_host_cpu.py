@@ -172,3 +172,32 @@ def test_enhancers_builder_matches_reference_rows(tmp_path):
     assert r.returncode == 0, r.stderr
     built = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path)) for f in fs if f.endswith('.tecidx')]
     assert len(built) == 1 and len(FlatIndex.load(built[0])) == 36
+
+
+def test_whitelist_loader_equals_the_reference_expression(tmp_path):
+    """te_count.py:330-339 is sorted(set(line.strip() for line in file)); the loader does it on bytes with numpy
+    (uniform files as one array, anything else line by line) and must give the same list and the same packing."""
+    import random
+    from te_counter_amd import reads
+    rnd = random.Random(3)
+    uniform = [''.join(rnd.choice('ACGT') for _ in range(16)) for _ in range(5000)]
+    cases = {
+        'uniform': '\n'.join(uniform + uniform[:100]) + '\n',
+        'no_final_newline': '\n'.join(uniform[:50]),
+        'ragged': '\n'.join(uniform[:50] + ['  ACGT \t', '', 'ACGT', 'AC', 'ACGTACGTACGTACGTACGTACGT']) + '\n',
+        'crlf': '\r\n'.join(uniform[:20]) + '\r\n',
+        'blank_lines': 'AAAA\n\n\nCCCC\n',
+        'empty': '',
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + '.txt')
+        p.write_text(text)
+        want = sorted(set(line.strip() for line in open(p)))
+        names, packed = reads.load_whitelist(str(p))
+        assert list(names) == want, name
+        assert len(names) == len(want) and (not want or names[len(want) // 2] == want[len(want) // 2])
+        assert np.array_equal(packed, reads.pack_whitelist(want)), name
+    p = tmp_path / 'long.txt'
+    p.write_text('A' * 25 + '\n')
+    with pytest.raises(ValueError):
+        reads.load_whitelist(str(p))
