@@ -18,4 +18,5 @@ for rep in 1 2 3; do
   t1=$(date +%s.%N)
   python3 -c "print('te_count process: %.2f s wall' % ($t1 - $t0))"
 done
+for rep in 1 2; do t0=$(date +%s.%N); python3 tools/cli_phases.py; t1=$(date +%s.%N); python3 -c "print('phase script process: %.2f s wall' % ($t1 - $t0))"; done
 rm -f /dev/shm/w.bam /dev/shm/w.tecidx /dev/shm/w.tsv
