@@ -2,10 +2,12 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := $(wildcard te_counter_amd/csrc/*.hip)
-HDRS  := $(wildcard te_counter_amd/csrc/*.h) include/tecount.h
+HDRS  := $(wildcard te_counter_amd/csrc/*.h) include/tecount.h Makefile
 OBJS  := $(patsubst te_counter_amd/csrc/%.hip,build/%.o,$(CSRC))
 LIB   := te_counter_amd/libtecount.so
-FLAGS := $(EXTRA) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -Iinclude
+# packed FP32 instructions are switched off for the device pass (hipcc's host pass does not know the feature and says so)
+FLAGS := $(EXTRA) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -Iinclude \
+         -Xclang -target-feature -Xclang -packed-fp32-ops
 
 all: $(LIB) oracle
 

@@ -171,7 +171,8 @@ int tec_bulk_reduce_time(tec_ctx* ctx, double* total_ms);
  * record: cls = id of the read-side chromosome string reference_name.replace('chr','')
  * (te_count.py:431), pos/end = reference_start/reference_end, flag, mapq, the CB (else CR) and
  * UB (else UR) tag values as zero-padded 24-byte fields, and tagflags (bit 0: CB|CR present,
- * bit 1: UB|UR present, bit 2: barcode longer than 24 bytes).  Everything the reference keeps in
+ * bit 1: UB|UR present, bit 2: barcode longer than 24 bytes, bit 3: UMI longer than 24 bytes -- a
+ * record that reaches the (CB,UB) collapse with bit 3 set makes tec_sc_part1 fail with TEC_EOVERFLOW).  Everything the reference keeps in
  * dicts, sets and spill files stays in HBM; the spill ("bundle") boundaries, the bundle reader's
  * line-drop rule and the cross-bundle merge are reproduced exactly.
  *
@@ -232,6 +233,9 @@ int tec_sc_survivors_replace(tec_ctx* ctx, uint64_t n, const uint32_t* bcid, con
                              const int32_t* rite);
 int tec_sc_part1_sort(tec_ctx* ctx, uint64_t* n_keys);
 int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t* first_no_ub);
+/* Ordinal of the first surviving record whose UMI does not fit the 24-byte field (~0: none); after tec_sc_part1_sort.
+ * (The reference keeps UMIs as Python strings of any length, te_count.py:420-427; this library refuses such a run.) */
+int tec_sc_long_umi(tec_ctx* ctx, uint64_t* first);
 int tec_sc_epoch_marks(tec_ctx* ctx, int64_t lower, uint64_t* n_marks);
 int tec_sc_epoch_rank(tec_ctx* ctx, uint64_t v, uint64_t* count_le);
 int tec_sc_epoch_kth(tec_ctx* ctx, uint64_t k, uint64_t* ordinal);

@@ -211,6 +211,50 @@ def run_make_custom(gtf_path):
     return rows
 
 
+def run_custom_end_to_end(gtf_path, records, paired, quality_threshold=20):
+    """What a user of the reference does for a custom annotation, in one go: te_genome -m custom --gtf F
+    (te_count/genome/make.py:173-226) writes the .glb, te_count -g that.glb -m custom binds and loads it
+    (bin/te_count:80-84,112) and counts (te_count.py:42-296).  Returns dict(result, total_reads, tsv)."""
+    tc = load_reference()
+    with tempfile.TemporaryDirectory() as td:
+        glb = os.path.join(td, 'custom.glb')
+        stdout, stderr = sys.stdout, sys.stderr
+        sys.stdout = io.StringIO()  # the builder prints progress bars
+        sys.stderr = io.StringIO()
+        try:
+            tc.genome.make_custom(gtf_path, glb, _quiet_log())
+        finally:
+            sys.stdout, sys.stderr = stdout, stderr
+        m = tc.measureTE('harness', quality_threshold)
+        m.bind_genome(glb)
+        m.load_genome()
+        _FakeAlignmentFile.records = records
+        log = _quiet_log()
+        res = (m.parse_bampe if paired else m.parse_bamse)('x.bam', strand=False, log=log)
+        out = os.path.join(td, 'out.tsv')
+        m.save_result_bulk(res, out, log=log)
+        with open(out, 'rb') as fh:
+            tsv = fh.read().decode()
+    return {'result': res, 'total_reads': m.total_reads, 'tsv': tsv}
+
+
+def run_bulk_on_glb(glb_path, records, paired, quality_threshold=20):
+    """te_count -g FILE.glb -m custom on an index file that already exists (bin/te_count:80-84)."""
+    tc = load_reference()
+    with tempfile.TemporaryDirectory() as td:
+        m = tc.measureTE('harness', quality_threshold)
+        m.bind_genome(glb_path)
+        m.load_genome()
+        _FakeAlignmentFile.records = records
+        log = _quiet_log()
+        res = (m.parse_bampe if paired else m.parse_bamse)('x.bam', strand=False, log=log)
+        out = os.path.join(td, 'out.tsv')
+        m.save_result_bulk(res, out, log=log)
+        with open(out, 'rb') as fh:
+            tsv = fh.read().decode()
+    return {'result': res, 'total_reads': m.total_reads, 'tsv': tsv}
+
+
 def run_make_snrnps(genome, gencode_gz):
     """The reference's make_snrnps (make.py:228-288) on a local GENCODE file (same os proxy as
     run_make_genes_tes)."""

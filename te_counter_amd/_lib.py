@@ -67,6 +67,7 @@ _SIGNATURES = {
     'tec_sc_survivors_replace': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),
     'tec_sc_part1_sort': (C.c_int, [_p, C.POINTER(_u64)]),
     'tec_sc_missing_tags': (C.c_int, [_p, C.POINTER(_u64), C.POINTER(_u64)]),
+    'tec_sc_long_umi': (C.c_int, [_p, C.POINTER(_u64)]),
     'tec_sc_epoch_marks': (C.c_int, [_p, C.c_int64, C.POINTER(_u64)]),
     'tec_sc_epoch_rank': (C.c_int, [_p, _u64, C.POINTER(_u64)]),
     'tec_sc_epoch_kth': (C.c_int, [_p, _u64, C.POINTER(_u64)]),

@@ -138,6 +138,12 @@ def main(argv=None):
     world = dist.World.from_env()
     try:
         device = job.device if job.device is not None else world.local_rank
+        if world.size > 1 and world.backend == 'nccl' and device != world.local_rank:
+            # RCCL reduces the count vector where it lives: the process group is bound to GPU LOCAL_RANK, and a
+            # buffer on another GPU cannot take part in it
+            raise SystemExit('te_count: --device %d conflicts with LOCAL_RANK %d (one process per GPU; leave --device '
+                             'out under torch.distributed.run, or set TEC_DIST_BACKEND=gloo to share GPUs)'
+                             % (device, world.local_rank))
         mte = measureTE(sys.argv[0], job.qual, device=device, world=world)
         mte.bind_genome(_resolve_index(job, log))
         (_run_single_cell if job.single_cell else _run_bulk)(mte, job, world, log)

@@ -599,16 +599,20 @@ static int bam_open_impl(const char* path, int n_threads, uint64_t range_begin, 
             bool found = false;
             for (;;) {
                 const size_t n = r->buf.size();
-                for (; x + 36 <= n && !found; ++x)
+                const size_t lim = std::min(n, own_limit(r));  // the record must start in an owned block
+                for (; x < lim && x + 36 <= n && !found; ++x)
                     if (tec_bamscan::plausible_record(r->buf.data(), n, x, (int32_t)r->ref_names.size(), lens.data(), 3)) {
-                        // the record must start in an owned block
                         found = true;
                         break;
                     }
-                if (found || r->owned_done || r->eof) break;
+                if (found || r->eof || (r->owned_done && x >= lim)) break;
+                // a start position in the last bytes of the owned blocks can only be judged with the bytes behind it
+                if (r->owned_done) r->in_epilogue = true;
                 rc = refill_keep(r, 4);
                 if (rc < 0) return bail(rc);
+                if (rc == 0) break;
             }
+            r->in_epilogue = false;
             if (found) {
                 r->buf_pos = x;
                 bool in_owned = false;

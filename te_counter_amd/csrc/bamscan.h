@@ -5,7 +5,7 @@
 // 204-214, 394-438); pysam / htslib are not part of the reference tree, so the rules are the SAM/BAM
 // specification's (SAMv1 section 4.2) plus the two htslib behaviours that change a value the
 // reference consumes: bam_endpos() counts a CIGAR without reference-consuming ops as one base, and
-// a long CIGAR parked in a CG:B,I tag behind the placeholder <l_seq>S<n>N is the record's real CIGAR.
+// a long CIGAR parked in a CG:B,I tag behind a placeholder CIGAR that starts with <l_seq>S is the record's real CIGAR.
 #pragma once
 
 #include <cstdint>
@@ -149,10 +149,11 @@ TEC_HD bool parse_core(const uint8_t* rec, bool want_end, Core* c) {
         int64_t reflen;
         const uint8_t* cg = nullptr;
         uint32_t cg_n = 0;
-        // htslib (sam.c bam_tag2cigar): the placeholder CIGAR <l_seq>S<n>N stands for the ops in CG:B,I
-        if (c->n_cigar == 2u && c->tid >= 0 && c->pos >= 0) {
+        // htslib (sam.c bam_tag2cigar): a CIGAR whose first op is <l_seq>S on a placed read is a placeholder for the ops in
+        // the record's first CG tag, if that is a B array of (u)int32 holding at least n_cigar_op (and fewer than 2^29) ops
+        if (c->tid >= 0 && c->pos >= 0) {
             const uint32_t op0 = rd32(c->cigar);
-            if ((op0 & 15u) == 4u && (op0 >> 4) == c->l_seq && (rd32(c->cigar + 4) & 15u) == 3u) {
+            if ((op0 & 15u) == 4u && (op0 >> 4) == c->l_seq) {
                 const uint8_t* a = c->aux;
                 while (c->rec_end - a >= 3) {
                     const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
@@ -160,7 +161,7 @@ TEC_HD bool parse_core(const uint8_t* rec, bool want_end, Core* c) {
                     if (t0 == 'C' && t1 == 'G') {
                         if (ty == 'B' && c->rec_end - a >= 5 && (a[0] == 'I' || a[0] == 'i')) {
                             const uint32_t n = rd32(a + 1);
-                            if ((uint64_t)(c->rec_end - a - 5) >= 4ull * n) {
+                            if (n >= c->n_cigar && n < (1u << 29) && (uint64_t)(c->rec_end - a - 5) >= 4ull * n) {
                                 cg = a + 5;
                                 cg_n = n;
                             }

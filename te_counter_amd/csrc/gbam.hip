@@ -207,8 +207,7 @@ __global__ __launch_bounds__(64) void extract_kernel(const uint8_t* __restrict__
         }
         if (MODE == kModeSC || MODE == kModeDump) {
             const uint32_t tf = tec_bamscan::scan_tags(core.aux, core.rec_end, out.cb + 24 * w, out.ub + 24 * w);
-            out.tf[w] = (uint8_t)tf;
-            if (MODE == kModeSC && (tf & 8u)) atomicAdd(bad_layout + 1, 1u);  // a UMI longer than the 24-byte field
+            out.tf[w] = (uint8_t)tf;  // (bit 3, a UMI longer than the 24-byte field, is judged by the single-cell filter)
         }
     }
 }
@@ -897,12 +896,8 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     if (rc != TEC_OK) return tec_fail(ctx, rc, "%s", tec_bam_last_error(nullptr));
     std::unique_ptr<tec_gbam> g(new tec_gbam());
     g->ctx = ctx;
-    if (ctx->gbam_cache) {  // buffers parked by the previous reader on this context
-        GbamBuffers* c = static_cast<GbamBuffers*>(ctx->gbam_cache);
-        static_cast<GbamBuffers&>(*g) = *c;
-        delete c;
-        ctx->gbam_cache = nullptr;
-    }
+    // (the buffers parked on the context by the previous reader are taken over at the very end: an open that fails
+    // leaves them where they are)
     const int n_ref = tec_bam_n_refs(hb);
     for (int i = 0; i < n_ref; ++i) g->ref_names.emplace_back(tec_bam_ref_name(hb, i));
     g->ref_lens.resize((size_t)n_ref);
@@ -970,7 +965,17 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
                                 kInflThreads * (int)tec_ginf::kEntriesPerLane * 2);
     if (e != hipSuccess) {
         close(g->fd);
+        g->d_reflen.release();
         return tec_fail(ctx, TEC_EHIP, "tec_gbam_open: %s", hipGetErrorString(e));
+    }
+    if (ctx->gbam_cache) {  // buffers parked by the previous reader on this context
+        GbamBuffers* c = static_cast<GbamBuffers*>(ctx->gbam_cache);
+        DBuf own_reflen = g->d_reflen;  // (just filled; the parked one is dropped in its favour)
+        static_cast<GbamBuffers&>(*g) = *c;
+        g->d_reflen.release();
+        g->d_reflen = own_reflen;
+        delete c;
+        ctx->gbam_cache = nullptr;
     }
     *out = g.release();
     return TEC_OK;
@@ -1271,7 +1276,6 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     G_HIP(hipStreamSynchronize(cs));
     G_HIP(hipMemcpy(h, flags.p, sizeof h, hipMemcpyDeviceToHost));
     if ((uint32_t)h[2]) return gfail(g, TEC_EINVAL, "corrupt BAM record layout");
-    if ((uint32_t)(h[2] >> 32)) return gfail(g, TEC_EOVERFLOW, "UMI longer than 24 bytes is not supported");
     if (rep) {
         memset(rep, 0, sizeof *rep);
         rep->n_records = g->n_records;

@@ -63,7 +63,7 @@ struct dvec {
     }
 };
 
-enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_OR0, ST_OR1, ST_OR2, ST_NOSTRAND, ST_N };
+enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_LONGUMI, ST_OR0, ST_OR1, ST_OR2, ST_NOSTRAND, ST_N };
 
 }  // namespace
 
@@ -200,6 +200,9 @@ __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* _
                 } else {
                     ok = true;
                     bcid_out[i] = (uint32_t)id;
+                    // bit 3: a UMI longer than the 24-byte field.  Only a record that reaches the (CB,UB) collapse makes
+                    // the run fail: the reference never looks at the UMI of a record it has dropped before (te_count.py:394-433)
+                    if (tf & 8u) atomicMin(&stat[ST_LONGUMI], (unsigned long long)(rec_base + i));
                 }
             }
         }
@@ -727,7 +730,7 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
     }
     SC_HIP(s->stat.reserve(ST_N));
     unsigned long long init[ST_N] = {0};
-    init[ST_NOCB] = init[ST_NOUB] = ~0ull;
+    init[ST_NOCB] = init[ST_NOUB] = init[ST_LONGUMI] = ~0ull;
     SC_HIP(hipMemcpy(s->stat.p, init, sizeof init, hipMemcpyHostToDevice));
     return TEC_OK;
 }
@@ -1133,6 +1136,15 @@ extern "C" int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t
     return TEC_OK;
 }
 
+/* ordinal of the first record that reaches the (CB,UB) collapse with a UMI longer than the 24-byte field (tagflags bit
+ * 3), ~0 if none: such a run is refused (TEC_EOVERFLOW from tec_sc_part1); valid after tec_sc_part1_sort */
+extern "C" int tec_sc_long_umi(tec_ctx* ctx, uint64_t* first) {
+    if (!ctx || !ctx->sc || !ctx->sc->sorted || !first) return tec_fail(ctx, TEC_ESTATE, "tec_sc_long_umi: call tec_sc_part1_sort first");
+    tec_sc_state* s = ctx->sc;
+    *first = s->h_stat[ST_LONGUMI] == ~0ull ? ~0ull : s->h_stat[ST_LONGUMI] + s->rec_base;
+    return TEC_OK;
+}
+
 extern "C" int tec_sc_epoch_marks(tec_ctx* ctx, int64_t lower, uint64_t* n_marks) {
     int rc = sc_check_open(ctx, "tec_sc_epoch_marks", true);
     if (rc) return rc;
@@ -1199,6 +1211,10 @@ extern "C" int tec_sc_part1(tec_ctx* ctx, uint64_t* n_cells_seen) {
         if (s->h_stat[ST_NOCB] < s->h_stat[ST_NOUB])
             return tec_fail(ctx, TEC_ENOCB, "CB or CR tag not found! (record %llu)", s->h_stat[ST_NOCB]);
         return tec_fail(ctx, TEC_ENOUB, "UB or UR tag not found! (record %llu)", s->h_stat[ST_NOUB]);
+    }
+    if (s->h_stat[ST_LONGUMI] != ~0ull) {
+        s->part1_done = true;
+        return tec_fail(ctx, TEC_EOVERFLOW, "UMI longer than 24 bytes is not supported (record %llu)", s->h_stat[ST_LONGUMI]);
     }
     PhaseTimer timer(ctx, s);
     // bundles (te_count.py:377-390): the flush fires once len(umis) has reached bundle_keys

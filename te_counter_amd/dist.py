@@ -113,16 +113,24 @@ class World:
 def check_ranges(reports, file_size):
     """reports: per rank {'has_records', 'first_token', 'end_token'} in rank order.  The ranges tile the
     file iff every range's end token (where the first record it does NOT own starts) is the first
-    token of the next range that has records, and the last one ends at the end of the file."""
+    token of the next range that has records, and the last one ends at the end of the file.
+    Range 0 knows where the file's first record starts (right behind the BAM header) and reports that as
+    its first token even when it owns no record itself (a header larger than its share of a small file):
+    the first range that does have records must start exactly there, so its speculative start is checked
+    like every other one."""
     prev = None
     for r, rep in enumerate(reports):
         if not rep['has_records']:
+            if r == 0 and tuple(rep['first_token']) != (0, 0):
+                prev = (0, rep['first_token'])  # the header's token stands in for "range 0 ends here"
             continue
         if prev is not None and tuple(prev[1]) != tuple(rep['first_token']):
             raise RuntimeError('byte-range decoding is inconsistent: range %d ends at %r but range %d starts at %r '
                                '(a record-boundary guess was wrong; rerun on one GPU)'
                                % (prev[0], tuple(prev[1]), r, tuple(rep['first_token'])))
         prev = (r, rep['end_token'])
+    if not any(rep['has_records'] for rep in reports):
+        return
     if prev is not None and tuple(prev[1]) != (file_size, 0):
         raise RuntimeError('byte-range decoding is inconsistent: the last range ends at %r, not at the end of the file' % (tuple(prev[1]),))
 

@@ -24,6 +24,7 @@ class Engine:
         self._keep = []  # host arrays of in-flight submits
         self._pinned = []  # (address, ctypes buffer) of every tec_alloc_pinned block: freed at close()
         self._ring, self._ring_cap, self._ring_slot = None, 0, 0
+        self._ring_ticket = [0, 0, 0]  # ticket of the submit that last copied out of each pinned slot
 
     def close(self):
         if self._ctx:
@@ -58,9 +59,16 @@ class Engine:
             self._ring = [tuple(self.pinned_empty(cap, dt) for dt in (np.int32, np.int32, np.int32, np.uint16, np.uint8))
                           for _ in range(3)]
             self._ring_cap = cap
-        slot = self._ring[self._ring_slot]
-        self._ring_slot = (self._ring_slot + 1) % 3
-        return slot
+            self._ring_ticket = [0, 0, 0]
+        k = self._ring_slot
+        self._ring_slot = (k + 1) % 3
+        if self._ring_ticket[k]:
+            # the H2D copy that last read this pinned slot must have finished before the host writes into it again
+            # (tec_bulk_wait = hipEventSynchronize on that batch's copy event: a host-side wait, unlike the
+            # stream-side dependency that protects the device slot)
+            self._check(self._lib.tec_bulk_wait(self._ctx, self._ring_ticket[k]))
+            self._ring_ticket[k] = 0
+        return self._ring[k], k
 
     def __del__(self):
         try:
@@ -87,6 +95,7 @@ class Engine:
     # ------------------------------------------------------------------ bulk
     def bulk_begin(self, mapq_min):
         self._keep = []
+        self._ring_ticket = [0, 0, 0]  # (tec_bulk_begin drains both streams)
         self._check(self._lib.tec_bulk_begin(self._ctx, int(mapq_min)))
 
     def bulk_submit(self, chrom, p1, p2, flag, mapq, stage=True):
@@ -104,16 +113,23 @@ class Engine:
             if n > self._ring_cap:  # the slots are replaced: nothing may still be copying out of the old ones
                 self._check(self._lib.tec_bulk_sync(self._ctx))
                 self._keep = []
-            slot = self._staging_slot(n)
+            slot, ring_k = self._staging_slot(n)
             for dst, src in zip(slot, arrs):
                 dst[:n] = src
             arrs = tuple(dst[:n] for dst in slot)
+        else:
+            ring_k = None
         t = C.c_uint64()
         self._check(self._lib.tec_bulk_submit(self._ctx, n, *[_ptr(a) for a in arrs], C.byref(t)))
-        self._keep.append(arrs)
-        if len(self._keep) > 2:  # a slot ring of 3: the oldest copy has certainly been consumed
-            self._check(self._lib.tec_bulk_wait(self._ctx, t.value - 2))
-            self._keep.pop(0)
+        if ring_k is not None:
+            self._ring_ticket[ring_k] = t.value
+        else:
+            # caller-owned arrays: kept alive until their copy has finished (the device ring is three deep, so
+            # by the time ticket t is queued the copy of ticket t - 2 is waited for and its arrays let go)
+            self._keep.append(arrs)
+            if len(self._keep) > 2:
+                self._check(self._lib.tec_bulk_wait(self._ctx, t.value - 2))
+                self._keep.pop(0)
         return t.value
 
     def bulk_submit_device(self, n, d_chrom, d_p1, d_p2, d_flag, d_mapq):
@@ -124,6 +140,7 @@ class Engine:
     def bulk_sync(self):
         self._check(self._lib.tec_bulk_sync(self._ctx))
         self._keep = []
+        self._ring_ticket = [0, 0, 0]
 
     def bulk_device_buffers(self):
         dc, ds = C.c_void_p(), C.c_void_p()
@@ -139,6 +156,7 @@ class Engine:
         st = _lib.Stats()
         rc = self._lib.tec_bulk_finish(self._ctx, _ptr(counts), C.byref(st))
         self._keep = []
+        self._ring_ticket = [0, 0, 0]
         enhancer_only = rc == _lib.TEC_EENHANCER
         if enhancer_only and raise_enhancer:
             raise NameError("name 'barcode' is not defined")
@@ -235,6 +253,11 @@ class Engine:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._lib.tec_sc_missing_tags(self._ctx, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def sc_long_umi(self):
+        a = C.c_uint64()
+        self._check(self._lib.tec_sc_long_umi(self._ctx, C.byref(a)))
+        return int(a.value)
 
     def sc_epoch_marks(self, lower):
         n = C.c_uint64()

@@ -294,17 +294,15 @@ def sc_batch_arrays(batch, tid_class):
     """RecordBatch -> the arrays tec_sc_submit takes."""
     n = len(batch)
     if batch.tagflags is not None:
-        cb, ub, tagflags = batch.cb24, batch.ub24, batch.tagflags
-        if (tagflags & 8).any():
-            raise ValueError('UMI longer than %d bytes is not supported' % TAG_BYTES)
+        cb, ub, tagflags = batch.cb24, batch.ub24, batch.tagflags  # (bit 3, an over-long UMI, is judged on the GPU)
     else:
         if batch.cb is None or batch.ub is None:
             raise ValueError('this alignment source does not carry CB/UB tags')
         cb, cb_present, cb_long = pack_tags(batch.cb, 'CB')
         ub, ub_present, ub_long = pack_tags(batch.ub, 'UB')
-        if ub_long.any():
-            raise ValueError('UMI longer than %d bytes is not supported' % TAG_BYTES)
-        tagflags = (cb_present.astype(np.uint8) | (ub_present.astype(np.uint8) << 1) | (cb_long.astype(np.uint8) << 2))
+        # an over-long UMI (bit 3) only matters on a record that survives every filter: the GPU decides (sc_filter_kernel)
+        tagflags = (cb_present.astype(np.uint8) | (ub_present.astype(np.uint8) << 1) | (cb_long.astype(np.uint8) << 2) |
+                    (ub_long.astype(np.uint8) << 3))
     cls = np.where(batch.tid >= 0, tid_class[np.clip(batch.tid, 0, max(0, len(tid_class) - 1))], -1).astype(np.int32) \
         if len(tid_class) else np.full(n, -1, np.int32)
     return cls, batch.pos, batch.end, batch.flag, batch.mapq, cb, ub, tagflags

@@ -44,6 +44,8 @@ def run_parts(eng, world, n_records_local, bundle_keys, maxcells, pad):
     no_cb, no_ub = min(m[0] for m in missing), min(m[1] for m in missing)
     if no_cb != NONE64 or no_ub != NONE64:
         raise AssertionError('CB or CR tag not found!' if no_cb < no_ub else 'UB or UR tag not found!')
+    if min(world.gather(eng.sc_long_umi())) != NONE64:  # (a limit of this library, not of the reference)
+        raise ValueError('UMI longer than 24 bytes is not supported')
     # ---- bundle boundaries
     bounds, lower = [], -1
     if _dist.world_sum(world, n_keys) >= bundle_keys:

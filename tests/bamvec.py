@@ -141,6 +141,16 @@ def every_cigar_op_and_aux_type():
          {'tid': 1, 'pos': 1000, 'end': 1000 + 5 + 20 + 3 + 7, 'flag': 0, 'mapq': 40, 'cb': 'LC', 'ub': 'LU', 'tf': 3}),
         (record(0, 99990, 20, 0, 'last', '10M', aux_bytes=aux('CB', 'Z', 'Z') + aux('UB', 'Z', 'Z')),
          {'tid': 0, 'pos': 99990, 'end': 100000, 'flag': 0, 'mapq': 20, 'cb': 'Z', 'ub': 'Z', 'tf': 3}),
+        # htslib's bam_tag2cigar asks only for a first op <l_seq>S: a one-op placeholder is one too ...
+        (record(1, 2000, 40, 0, 'cg_one_op_placeholder', [(12, 4)], l_seq=12, aux_bytes=aux('CG', 'B', [(12 << 4) | 0, (30 << 4) | 3], 'I')),
+         {'tid': 1, 'pos': 2000, 'end': 2042, 'flag': 0, 'mapq': 40, 'cb': '', 'ub': '', 'tf': 0}),
+        # ... a CG array shorter than the placeholder is ignored (12S 999N stays: 999 reference bases) ...
+        (record(1, 3000, 40, 0, 'cg_shorter_than_fake', [(12, 4), (999, 3)], l_seq=12, aux_bytes=aux('CG', 'B', [(5 << 4) | 0], 'I')),
+         {'tid': 1, 'pos': 3000, 'end': 3999, 'flag': 0, 'mapq': 40, 'cb': '', 'ub': '', 'tf': 0}),
+        # ... an unplaced read keeps its CIGAR as it stands, and a UMI of more than 24 bytes is flagged (bit 3), not fatal here
+        (record(-1, -1, 0, 4, 'cg_unplaced_long_umi', [(12, 4), (7, 3)], l_seq=12,
+                aux_bytes=aux('CG', 'B', [(5 << 4) | 0, (3 << 4) | 0], 'I') + aux('CB', 'Z', 'Q') + aux('UB', 'Z', 'U' * 25)),
+         {'tid': -1, 'pos': -1, 'end': 6, 'flag': 4, 'mapq': 0, 'cb': 'Q', 'ub': '', 'tf': 1 | 2 | 8}),
     ]
     payload = header(refs)
     hdr_len = len(payload)
@@ -161,5 +171,5 @@ def check_rows(arrays, want):
             assert int(arrays['tagflags'][i]) == w['tf'], (i, int(arrays['tagflags'][i]), w)
             if w['tf'] & 1 and not w['tf'] & 4:
                 assert bytes(arrays['cb24'][i]).rstrip(b'\0').decode() == w['cb'], i
-            if w['tf'] & 2:
+            if w['tf'] & 2 and not w['tf'] & 8:
                 assert bytes(arrays['ub24'][i]).rstrip(b'\0').decode() == w['ub'], i

@@ -158,10 +158,12 @@ def make_sc_records(seed, n, whitelist, features=None, span=200000, n_cells=12, 
     return recs[:n] if len(recs) > n else recs
 
 
-def make_gtf_text(seed, n_genes=40):
+def make_gtf_text(seed, n_genes=40, numeric_ids=True):
     """A GTF with the quirks the reference's reader cares about: comment lines, non-exon rows,
     contigs outside chr1-29/X/Y, dotted / numeric-looking ids, quoted and unquoted values, a
-    trailing ';' on the last attribute, extra attributes."""
+    trailing ';' on the last attribute, extra attributes.  numeric_ids=False leaves out the gene ids
+    that the reference's reader turns into ints (an index holding both ints and strings cannot be
+    loaded by the reference: sorted() of mixed types, te_count.py:35)."""
     rng = random.Random(seed)
     lines = ['##description: synthetic', '#!genome-build test']
     chroms = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chrUn_KI270742v1', 'chr1_KI270706v1_random', 'chr7', '12']
@@ -170,6 +172,8 @@ def make_gtf_text(seed, n_genes=40):
         c = rng.choice(chroms)
         start = rng.randrange(1, 150000)
         gid = rng.choice(['ENSG%011d.%d' % (g, rng.randrange(1, 9)), 'ENH%07d' % g, 'gene_%d' % g, '%d' % (1000 + g)])
+        if not numeric_ids and gid.isdigit():
+            gid = 'ENH%07d' % g
         gname = rng.choice(['Gene%d' % g, 'GENE-%d' % g, 'G%d.1' % g])
         gtype = rng.choice(types)
         strand = rng.choice('+-')

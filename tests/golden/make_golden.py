@@ -220,5 +220,34 @@ def main():
         json.dump(feats, fh)
 
 
+def end_to_end_index_cases():
+    """Index files end to end through the reference: (1) a GTF -> the reference's make_custom -> .glb -> bulk SE and
+    PE counts -> TSV; (2) the committed reference-built ref_built_index.glb -> bulk SE counts -> TSV."""
+    gtf_path = os.path.join(HERE, 'custom_e2e.gtf')
+    with open(gtf_path, 'w') as fh:
+        fh.write(dg.make_gtf_text(37, 60, numeric_ids=False))
+    rows = rh.run_make_custom(gtf_path)
+    assert all(isinstance(r['ensg'], str) for r in rows)
+    for paired in (False, True):
+        recs = [r for r in dg.make_records(371 + paired, 3000, rows, span=160000, paired=paired) if r['end'] > r['pos']]
+        if paired and len(recs) % 2:
+            recs.pop()
+        ref = rh.run_custom_end_to_end(gtf_path, recs, paired)
+        assert sum(ref['result'].values()) > 0
+        dump('custom_e2e_%s' % ('pe' if paired else 'se'),
+             {'kind': 'custom_e2e', 'gtf_file': 'custom_e2e.gtf', 'records': recs, 'params': {'paired': paired, 'q': 20},
+              'expected': {'rows': rows, 'result': ref['result'], 'total_reads': ref['total_reads'], 'tsv': ref['tsv']}})
+    feats = json.load(gzip.open(os.path.join(HERE, 'ref_built_index.features.json.gz'), 'rt'))
+    recs = [r for r in dg.make_records(91, 3000, feats) if r['end'] > r['pos']]
+    ref = rh.run_bulk_on_glb(os.path.join(HERE, 'ref_built_index.glb'), recs, False)
+    assert sum(ref['result'].values()) > 0
+    dump('glb_e2e_se', {'kind': 'glb_e2e', 'glb_file': 'ref_built_index.glb', 'records': recs, 'params': {'paired': False, 'q': 20},
+                        'expected': {'result': ref['result'], 'total_reads': ref['total_reads'], 'tsv': ref['tsv']}})
+
+
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['index_e2e']:  # only the index end-to-end fixtures (the others are byte-stable and stay)
+        end_to_end_index_cases()
+    else:
+        main()
+        end_to_end_index_cases()

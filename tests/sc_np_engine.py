@@ -109,6 +109,9 @@ class NpScEngine:
         f = lambda v: NONE64 if v == NONE64 else v + self.base  # noqa: E731
         return f(self.no_cb), f(self.no_ub)
 
+    def sc_long_umi(self):
+        return NONE64  # (the stand-in keeps UMIs of any length)
+
     def sc_epoch_marks(self, lower):
         rec = self.s['rec'].astype(np.int64)
         prev = np.concatenate([[-1], rec[:-1]])

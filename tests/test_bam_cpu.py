@@ -217,3 +217,42 @@ def test_hand_assembled_vectors_byte_ranges(tmp_path):
         got = {k: np.concatenate([getattr(b, k) for b in rows]) for k in ('tid', 'pos', 'end', 'flag', 'mapq', 'cb24', 'ub24', 'tagflags')}
         bamvec.check_rows(got, want)
         dist.check_ranges(reports, size)
+
+
+def test_first_range_without_records_still_pins_the_first_record(tmp_path):
+    """A header larger than range 0's share of the file: range 0 owns no record, and the first range that does
+    starts from a guess.  Range 0 reports the header's first-record token, so check_ranges verifies that guess too
+    -- and refuses a forged one."""
+    import bamvec
+    from te_counter_amd import dist
+    refs = [('contig_with_a_long_name_%04d' % i, 100000 + i) for i in range(120)]
+    payload = bamvec.header(refs)
+    hdr_len = len(payload)
+    n_rec = 60
+    for i in range(n_rec):
+        payload += bamvec.record(i % 120, 10 * i, 30, 0, 'read%03d/1' % i, '20M', aux_bytes=bamvec.aux('NH', 'i', 1))
+    p = tmp_path / 'bighdr.bam'
+    bamvec.write_blocks(str(p), payload, list(range(300, len(payload), 300)), level=1)
+    size = os.path.getsize(str(p))
+    seen_empty_first = False
+    for world in (2, 3, 4):
+        reports, pos = [], []
+        for r in range(world):
+            src = bam.BamSource(str(p), byte_range=bam.byte_range(size, r, world), batch_size=7, threads=1)
+            got = [b.pos for b in src._batches()]
+            first, end, has = src.range_tokens()
+            src.close()
+            n = sum(len(b) for b in got)
+            reports.append({'has_records': has and n > 0, 'first_token': first, 'end_token': end, 'n_records': n})
+            pos += got
+        assert np.concatenate(pos).tolist() == [10 * i for i in range(n_rec)]
+        dist.check_ranges(reports, size)
+        if not reports[0]['has_records']:
+            seen_empty_first = True
+            assert tuple(reports[0]['first_token']) != (0, 0)
+            k = next(i for i, rep in enumerate(reports) if rep['has_records'])
+            forged = [dict(rep) for rep in reports]
+            forged[k]['first_token'] = (forged[k]['first_token'][0], forged[k]['first_token'][1] + 1)
+            with pytest.raises(RuntimeError):
+                dist.check_ranges(forged, size)
+    assert seen_empty_first and hdr_len > size // 4

@@ -63,3 +63,26 @@ def test_quirks_are_present():
     # read 10000-19999 vs G2 10000-19999: b1=0, b2=2, G2 sits in bucket 1 only -> only 10000-10050 counts
     assert res['ENSG00002'] == 1
     assert g['expected']['total_reads'] == len(g['records']) + 1
+
+
+@pytest.mark.parametrize('name', ['custom_e2e_se', 'custom_e2e_pe', 'glb_e2e_se'])
+def test_index_end_to_end_fixtures(name):
+    """GTF -> make_custom -> count and .glb -> count as the reference ran them: this build's GTF reader gives the
+    reference's rows, its .glb importer the reference's features, and the oracle on them the reference's TSV."""
+    import gzip
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from te_counter_amd import genome
+    from te_counter_amd.index import FlatIndex
+    g = load_golden(name)
+    if g['kind'] == 'custom_e2e':
+        feats = genome.custom_features(os.path.join(GOLDEN_DIR, g['gtf_file']))
+        assert feats == g['expected']['rows']
+    else:
+        feats = json.load(gzip.open(os.path.join(GOLDEN_DIR, 'ref_built_index.features.json.gz'), 'rt'))
+        flat = FlatIndex.from_glb(os.path.join(GOLDEN_DIR, g['glb_file']))
+        assert flat.names == sorted(set(f['ensg'] for f in feats))
+    res, total, _ = orc.bulk_count(feats, g['records'], g['params']['paired'], g['params']['q'])
+    assert total == g['expected']['total_reads'] and res == g['expected']['result']
+    assert orc.format_bulk_tsv(res, total) == g['expected']['tsv']
