@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--records', type=int, default=125_000_000, help='BAM records per GPU per step')
     ap.add_argument('--genome', default='hg38', choices=['hg38', 'mm10', 'custom3m'],
@@ -64,8 +64,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...' % (args.gpus, args.gpus))
+        if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))  # a bare `python bench.py --gpus N`: start the N ranks ourselves
         sys.exit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     import torch
@@ -197,6 +197,24 @@ def main():
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run (one
+    process per GPU) as a CHILD process -- this process has not touched the GPU yet and never will -- pass rank 0's
+    JSON line through and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    child = subprocess.run(cmd, env=env)
+    return child.returncode
+
+
 class BulkRun:
     """An index replica on the engine's GPU and one HBM-resident batch of synthetic units."""
 
@@ -214,17 +232,36 @@ class BulkRun:
         self.ptrs = [d.data_ptr() for d in self.dev]
         torch.cuda.synchronize()
 
+    def reference_index_shape(self):
+        """The index as the reference holds it (te_count/miniglbase/genelist.py:367-378): one list entry per feature and
+        10 kb bucket it touches, one bucket list per 10 kb of every chromosome that has features."""
+        flat = self.ann.flat
+        bs = 10000
+        lo, hi = flat.left.astype(np.int64) // bs, flat.right.astype(np.int64) // bs
+        entries = int((hi - lo + 1).sum())
+        top = np.zeros(max(1, len(flat.chrom_keys)), np.int64)
+        np.maximum.at(top, flat.chrom_id, hi + 1)
+        return entries, int(top.sum())
+
     def algorithmic_bytes(self):
-        # 15 B per unit + index (12 B per entry + 4 B per bin) + 8 B per name
-        return 15.0 * self.n_units + 12.0 * self.info['n_entries'] + 4.0 * self.info['n_bins'] + 8.0 * self.eng.n_names
+        # 15 B per unit + the index once (12 B per bucket entry + 4 B per bucket, in the REFERENCE's shape: 10 kb
+        # buckets) + 8 B per name written
+        entries, buckets = self.reference_index_shape()
+        return 15.0 * self.n_units + 12.0 * entries + 4.0 * buckets + 8.0 * self.eng.n_names
 
     def roofline(self, kernel_ms, launches, reduce_ms, launch_ms, traffic):
+        traffic, traffic_source = traffic
         alg = self.algorithmic_bytes()
         avg_ms = kernel_ms / max(1, launches)
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        entries, buckets = self.reference_index_shape()
         r = {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'kernel': 'count_bulk_rec_kernel',
+             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_source,
+             'kernel': 'count_bulk_rec_kernel',
              'avg_launch_ms': round(avg_ms, 4), 'algorithmic_bytes_per_launch': alg,
+             'algorithmic_bytes': {'units': 15.0 * self.n_units, 'reference_shaped_index': 12.0 * entries + 4.0 * buckets,
+                                   'counts': 8.0 * self.eng.n_names,
+                                   'this_build_index_bytes_for_comparison': 12.0 * self.info['n_entries'] + 4.0 * self.info['n_bins']},
              'reduce_slabs_kernel_avg_ms': round(reduce_ms / max(1, launches), 4)}
         if len(launch_ms):  # per-launch durations from the event pool: the sample is short, show its spread
             r['launch_ms_min_median_max'] = [round(float(np.min(launch_ms)), 4), round(float(np.median(launch_ms)), 4),
@@ -253,6 +290,8 @@ def compact(out):
     o['config']['index'] = {k: out['config']['index'][k] for k in ('n_entries', 'n_bins')}
     pick = lambda d, keys: {k: d[k] for k in keys if k in d}  # noqa: E731
     rl = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'gpu_stream_ms', 'launch_ms_min_median_max')
+    if o['roofline'].get('traffic_source'):
+        o['roofline'] = dict(o['roofline'], traffic_source={k: v for k, v in o['roofline']['traffic_source'].items() if k != 'collected'})
     for k in ('cpu_baseline', 'cpu_baseline_c_1core', 'cpu_baseline_c_allcores'):
         if k in o and 'error' not in o[k]:
             o[k] = pick(o[k], ('value', 'unit', 'cores', 'kind'))
@@ -294,17 +333,37 @@ def leg(fn, *a):
         return {'error': '%s: %s' % (type(e).__name__, e)}
 
 
+def kernel_source_sha():
+    """Fingerprint of the sources the count kernel is built from: a traffic figure measured on another version of the
+    kernel is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('bulk.hip', 'index.hip', 'spill.hip', 'tecount_internal.h'):
+        with open(os.path.join(ROOT, 'te_counter_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_for(explicit, genome, layout, order, n_units):
-    """HBM bytes per launch of the count kernel from the committed rocprofv3 --pmc passes
-    (profiles/traffic.json, written by tools/traffic.py); null if this workload was not profiled."""
+    """-> (HBM bytes per launch of the count kernel, where the figure comes from).  The bytes are read from the
+    committed rocprofv3 --pmc passes (profiles/traffic.json, written by tools/traffic.py from separate FETCH_SIZE /
+    WRITE_SIZE / request-size passes over this very command line); null if this workload was not profiled, or was
+    profiled on a different version of the kernel sources."""
     if explicit:
-        return float(explicit)
+        return float(explicit), {'from': '--traffic'}
     try:
         table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except (OSError, ValueError):
-        return None
+        return None, None
     e = table.get('%s/%s/%s/%d' % (genome, layout, order, n_units))
-    return float(e['hbm_bytes_per_launch']) if e else None
+    if not e:
+        return None, None
+    src = {'profile_tag': e.get('tag'), 'kernel_symbol': e.get('kernel_symbol'), 'kernel_source_sha': e.get('kernel_source_sha'),
+           'collected': 'rocprofv3 --pmc, separate passes; FETCH_SIZE*1024 + 64*TCC_EA0_RDREQ_128B + WRITE_SIZE*1024'}
+    if e.get('kernel_source_sha') != kernel_source_sha():
+        src['stale'] = 'profiled on another version of the kernel sources: not reported'
+        return None, src
+    return float(e['hbm_bytes_per_launch']), src
 
 
 def host_stream(eng, units, n_units, rec_per_unit, batch=1 << 24, reps=3):

@@ -65,7 +65,10 @@ def main():
             table = json.load(open(tpath))
         except (OSError, ValueError):
             table = {}
-        table[key] = dict(out['hbm'], tag=tag)
+        sys.path.insert(0, root)
+        import bench
+        symbol = next((r['Name'] for r in out.get('kernel_stats', []) if 'count_bulk' in r['Name']), None)
+        table[key] = dict(out['hbm'], tag=tag, kernel_symbol=symbol, kernel_source_sha=bench.kernel_source_sha())
         json.dump(table, open(tpath, 'w'), indent=1, sort_keys=True)
     json.dump(out, open(os.path.join(root, 'profiles', '%s_summary.json' % tag), 'w'), indent=1, sort_keys=True)
     print(json.dumps({k: out[k] for k in ('hbm',) if k in out}))
