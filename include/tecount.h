@@ -137,6 +137,22 @@ int tec_bulk_submit_device(tec_ctx* ctx, uint64_t n_units, const int32_t* d_chro
 /* Wait for everything submitted so far. */
 int tec_bulk_sync(tec_ctx* ctx);
 
+/* One batch counted from start to finish WITHOUT ANY ALLOCATION.  No counterpart in the reference (which allocates
+ * Python objects per read): this entry point is for callers that cannot call hipMalloc -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation.  It is tec_bulk_begin + tec_bulk_submit_device +
+ * tec_bulk_finish for one device-resident batch, with the results left in HBM:
+ *   d_counts_out  n_names uint64, in the CALLER's name ids (as tec_bulk_finish delivers them); overwritten
+ *   d_stats_out   6 uint64 {units, assigned, lowq, badchrom, qcfail, units that hit only 'enhancer' features}
+ *                 (the last one non-zero is where tec_bulk_finish returns TEC_EENHANCER); may be NULL
+ *   stream        a hipStream_t, or NULL for the context's own compute stream; the call only queues work on it
+ * The scratch memory of the launch (per-workgroup histogram rows, an internal count vector, tallies) is a fixed array
+ * of 24.4 MiB inside the library's code object, one copy per GPU for the life of the process, shared by every call on
+ * that GPU: calls that overlap on one GPU race, and the limits are fixed -- at most 49 152 names in the index and 2^31
+ * units per call (TEC_EOVERFLOW beyond).  It neither needs nor disturbs an open tec_bulk_begin run. */
+int tec_bulk_count_noalloc(tec_ctx* ctx, uint64_t n_units, const int32_t* d_chrom_id, const int32_t* d_p1, const int32_t* d_p2,
+                           const uint16_t* d_flag, const uint8_t* d_mapq, int mapq_min, uint64_t* d_counts_out,
+                           uint64_t* d_stats_out, void* stream);
+
 /* Device address of the running uint64 count vector (n_names entries, in the library's INTERNAL name order, identical on every GPU that holds the same index; tec_bulk_finish maps it back to name ids) and of
  * the 5-word stats block {units, assigned, lowq, badchrom, qcfail}; for the caller's multi-GPU
  * sum-reduce (RCCL through torch.distributed).  Valid until tec_destroy / the next

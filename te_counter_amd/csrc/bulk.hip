@@ -813,6 +813,37 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     if (threadIdx.x < 5 && tally[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], (unsigned long long)tally[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// tec_bulk_count_noalloc: the one-shot variant for callers that cannot allocate.  Everything the launch needs
+// beyond the caller's inputs and outputs -- the per-workgroup histogram rows, the count vector in internal name
+// order (the carry bookkeeping of the LDS histogram adds to it) and the tallies -- lives in one file-scope device
+// array.  Each GPU holds its own copy for the life of the process; its address is looked up once per context
+// (hipGetSymbolAddress in tec_bulk_init) and only that pointer is ever handed to kernels.
+constexpr uint32_t kNoAllocMaxNames = 49152;                       // every name must have an LDS counter
+constexpr uint32_t kNoAllocMaxRows = 256;                          // workgroups of one launch
+constexpr uint64_t kNoAllocMaxUnits = 1ull << 31;
+constexpr size_t kNoAllocRowWords = kNoAllocMaxNames / 2;          // packed 16-bit counters
+constexpr size_t kNoAllocRowsBytes = (size_t)kNoAllocMaxRows * kNoAllocRowWords * sizeof(uint32_t);  // 24 MiB
+constexpr size_t kNoAllocCountsBytes = ((size_t)kNoAllocMaxNames + 2) * sizeof(unsigned long long);
+constexpr size_t kNoAllocStatsOff = kNoAllocRowsBytes + ((kNoAllocCountsBytes + 255) & ~size_t(255));
+constexpr size_t kNoAllocBytes = kNoAllocStatsOff + 256;
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
+__global__ __launch_bounds__(256) void noalloc_clear_kernel(unsigned long long* counts, uint32_t n_counts, unsigned long long* stats) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_counts) counts[i] = 0ull;
+    if (i < 8u) stats[i] = 0ull;
+}
+
+// internal (hotness) name order -> the caller's name ids; the five log counters and the enhancer-only tally
+__global__ __launch_bounds__(256) void noalloc_export_kernel(const unsigned long long* __restrict__ counts, const uint32_t* __restrict__ int2ext,
+                                                             uint32_t n_names, const unsigned long long* __restrict__ stats,
+                                                             unsigned long long* out_counts, unsigned long long* out_stats) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_names) out_counts[int2ext[i]] = counts[i];
+    if (i < 6u && out_stats) out_stats[i] = stats[i];
+}
+
 typedef void (*count_kernel_t)(tec_index_dev, const int32_t*, const int32_t*, const int32_t*, const uint16_t*,
                                const uint8_t*, uint64_t, int, unsigned long long*, unsigned long long*, uint32_t,
                                uint64_t, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*);
@@ -1008,6 +1039,12 @@ int tec_bulk_init(tec_ctx* ctx) {
                 for (int all = 0; all < 2; ++all)
                     TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(mixed != 0, u, rec, all != 0)),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)(kChromLds * sizeof(uint2)) - 64));
+    {   // this GPU's copy of the no-allocation scratch array: the device address, looked up with the device current
+        void* p = nullptr;
+        TEC_HIP(ctx, hipSetDevice(ctx->device));
+        TEC_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        ctx->noalloc_scratch = static_cast<unsigned char*>(p);
+    }
     const char* e = getenv("TEC_UNROLL");  // tuning knob: units carried per lane (1, 2, 4 or 8)
     const int u = e ? atoi(e) : 2;
     ctx->unroll = (u == 1 || u == 2 || u == 4) ? u : 2;
@@ -1150,6 +1187,58 @@ extern "C" int tec_bulk_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* c
     TEC_HIP(ctx, hipSetDevice(ctx->device));
     UnitPtrs d{chrom, p1, p2, flag, mapq};
     return launch_count(ctx, d, n);
+}
+
+// One batch, counted from start to finish, without a single allocation: see include/tecount.h.
+extern "C" int tec_bulk_count_noalloc(tec_ctx* ctx, uint64_t n, const int32_t* d_chrom, const int32_t* d_p1, const int32_t* d_p2,
+                                      const uint16_t* d_flag, const uint8_t* d_mapq, int mapq_min, uint64_t* d_counts_out,
+                                      uint64_t* d_stats_out, void* stream) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_count_noalloc: NULL context");
+    if (!ctx->have_index) return tec_fail(ctx, TEC_ESTATE, "tec_bulk_count_noalloc: no index resident (call tec_index_build)");
+    if (!ctx->noalloc_scratch) return tec_fail(ctx, TEC_ESTATE, "tec_bulk_count_noalloc: the scratch array was not resolved");
+    if (!d_counts_out) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_count_noalloc: NULL output");
+    if (n && (!d_chrom || !d_p1 || !d_p2 || !d_flag || !d_mapq)) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_count_noalloc: NULL array");
+    if (ctx->idx.n_names > kNoAllocMaxNames)
+        return tec_fail(ctx, TEC_EOVERFLOW, "tec_bulk_count_noalloc: the index has %u names, the fixed scratch array holds counters for %u",
+                        ctx->idx.n_names, kNoAllocMaxNames);
+    if (n > kNoAllocMaxUnits)
+        return tec_fail(ctx, TEC_EOVERFLOW, "tec_bulk_count_noalloc: %llu units in one call, at most %llu", (unsigned long long)n,
+                        (unsigned long long)kNoAllocMaxUnits);
+    TEC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->s_compute;
+    uint32_t* const rows = reinterpret_cast<uint32_t*>(ctx->noalloc_scratch);
+    unsigned long long* const counts = reinterpret_cast<unsigned long long*>(ctx->noalloc_scratch + kNoAllocRowsBytes);
+    unsigned long long* const stats = reinterpret_cast<unsigned long long*>(ctx->noalloc_scratch + kNoAllocStatsOff);
+    const uint32_t n_names = ctx->idx.n_names;
+    // the array keeps the last call's contents: what must start at zero is cleared by a small kernel (no memset node, so
+    // that a caller may capture the call)
+    hipLaunchKernelGGL(noalloc_clear_kernel, dim3((n_names + 2u + 255u) / 256u), dim3(256), 0, st, counts, n_names + 2u, stats);
+    if (n) {
+        const int unroll = ctx->unroll;
+        const uint64_t chunk = (uint64_t)unroll * kBlock;
+        const uint64_t want = (n + chunk - 1) / chunk;
+        const bool mixed = (ctx->idx.class_mask & ~kCountable) != 0 || ctx->force_mixed;
+        const uint32_t k_lds = n_names;  // (<= kNoAllocMaxNames: every name has its LDS counter, nothing spills)
+        const uint32_t words = (((k_lds + 1u) >> 1) + 3u) & ~3u;
+        const unsigned grid = (unsigned)std::min<uint64_t>(want, std::min<uint64_t>((uint64_t)ctx->n_cu, kNoAllocMaxRows));
+        uint64_t span = (n / ((uint64_t)grid * ctx->span_div) + chunk - 1) / chunk * chunk;
+        if (span < chunk) span = chunk;
+        const bool rec_ok = ctx->kernel_variant == 2 && ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3;
+        hipLaunchKernelGGL(pick_kernel(mixed, unroll, rec_ok ? ctx->rec_ne : 0, true), dim3(grid), dim3(kBlock), (uint32_t)(words * 4u), st,
+                           ctx->idx, d_chrom, d_p1, d_p2, d_flag, d_mapq, n, mapq_min, counts, stats, k_lds, span,
+                           (uint32_t)ctx->aggregate, rows, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
+        TEC_HIP(ctx, hipGetLastError());
+        SlabRows used{};
+        used.n[0] = grid;
+        const unsigned split = std::max(1u, std::min(grid / 64u, 32u));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((words + 255u) / 256u, split), dim3(256), 0, st, (const uint32_t*)rows, words, words,
+                           used, 1u, (uint32_t)kNoAllocMaxRows, counts);
+    }
+    hipLaunchKernelGGL(noalloc_export_kernel, dim3((std::max(n_names, 6u) + 255u) / 256u), dim3(256), 0, st, (const unsigned long long*)counts,
+                       (const uint32_t*)ctx->d_int2ext, n_names, (const unsigned long long*)stats,
+                       reinterpret_cast<unsigned long long*>(d_counts_out), reinterpret_cast<unsigned long long*>(d_stats_out));
+    TEC_HIP(ctx, hipGetLastError());
+    return TEC_OK;
 }
 
 extern "C" int tec_bulk_sync(tec_ctx* ctx) {

@@ -99,6 +99,7 @@ struct tec_ctx {
     int ablate = 0;  // diagnostics (TEC_ABLATE)
     uint32_t lds_bytes = 0;  // 0 = automatic
     int span_div = 8;
+    unsigned char* noalloc_scratch = nullptr;  // device address of this GPU's copy of bulk.hip's file-scope scratch array
     // spill list of hit names beyond the LDS histogram (bulk.hip FastSink, spill.hip)
     bool spill_enabled = true;
     uint32_t *d_spill = nullptr, *d_spill_counts = nullptr;

@@ -137,6 +137,14 @@ class Engine:
         self._check(self._lib.tec_bulk_submit_device(self._ctx, int(n), C.c_void_p(d_chrom), C.c_void_p(d_p1),
                                                      C.c_void_p(d_p2), C.c_void_p(d_flag), C.c_void_p(d_mapq)))
 
+    def bulk_count_noalloc(self, n, d_chrom, d_p1, d_p2, d_flag, d_mapq, mapq_min, d_counts_out, d_stats_out=0, stream=0):
+        """tec_bulk_count_noalloc: raw HBM addresses (ints) in and out; only queues work (synchronise the stream
+        before reading the outputs)."""
+        self._check(self._lib.tec_bulk_count_noalloc(self._ctx, int(n), C.c_void_p(d_chrom), C.c_void_p(d_p1), C.c_void_p(d_p2),
+                                                     C.c_void_p(d_flag), C.c_void_p(d_mapq), int(mapq_min),
+                                                     C.c_void_p(d_counts_out), C.c_void_p(d_stats_out or None),
+                                                     C.c_void_p(stream or None)))
+
     def bulk_sync(self):
         self._check(self._lib.tec_bulk_sync(self._ctx))
         self._keep = []
