@@ -449,7 +449,11 @@ extern "C" int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out,
         if (in_len) memcpy(padded.data(), in, in_len);
         std::unique_ptr<tec_ginf::HostMem> m(new tec_ginf::HostMem);
         memset(m.get(), 0x77, sizeof(tec_ginf::HostMem));
-        return tec_ginf::inflate_stream(padded.data(), (uint32_t)in_len, out, (uint32_t)out_len, *m) == tec_ginf::kOk ? TEC_OK : TEC_EINVAL;
+        // phase 1 (the lane's code) into a token array, phase 2 replayed sequentially
+        std::vector<uint32_t> tok((size_t)out_len + 4096);
+        tec_ginf::VectorSink sink{tok.data(), (uint32_t)tok.size()};
+        if (tec_ginf::inflate_stream(padded.data(), (uint32_t)in_len, out, (uint32_t)out_len, *m, sink) != tec_ginf::kOk) return TEC_EINVAL;
+        return tec_ginf::resolve_tokens(tok.data(), sink.n, out, (uint32_t)out_len) ? TEC_OK : TEC_EINVAL;
     }
     std::unique_ptr<tec_inflate::Tables> tabs(new tec_inflate::Tables);
     return tec_inflate::inflate_block(in, in_len, out, out_len, tabs.get()) ? TEC_OK : TEC_EINVAL;

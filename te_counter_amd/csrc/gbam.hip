@@ -6,9 +6,13 @@
 // into a ring of pinned buffers, walks the BGZF headers and sends the blocks to HBM on the copy stream
 // (stage_chunk).  Everything else runs on the MI355X:
 //
-//   ginflate_kernel     one lane inflates one BGZF block (ginflate.h: 16-bit Huffman tables in LDS,
-//                       320 B per lane -> 512 lanes per CU); a block the kernel refuses is redone by
-//                       the host's referee decoder (inflate_fast.h, then zlib) and patched in
+//   ginflate_kernel     phase 1 of the inflation: one LANE per BGZF block decodes the Huffman bit stream into 32-bit
+//                       tokens (ginflate.h: 16-bit tables in LDS, 320 B per lane -> 512 lanes per CU), four tokens per
+//                       16-byte store into 8 KiB pages drawn from a pool; the lane never touches the inflated stream
+//   gresolve_kernel     phase 2: one WAVE per block replays the tokens, 64 at a time: positions by a wave prefix sum,
+//                       literals stored at once, matches copied in rounds (a match goes as soon as its source lies
+//                       below the first match still pending).  A block that phase 1 refuses is redone by the host's
+//                       referee decoder (inflate_fast.h, then zlib) and patched in
 //   seg_guess_kernel    the inflated stream is cut into 64 KiB segments; one wave per segment looks for
 //                       the first offset at which a chain of BAM records plausibly starts (bamscan.h)
 //   seg_walk_kernel     one lane per segment walks the record chain from that offset to the segment's
@@ -84,9 +88,57 @@ struct DevMem {
     __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
 };
 
+// ---- token pages.  A block's tokens go, four per 16-byte group, into pages of kPageGroups groups that its lane draws
+// from a pool with one atomic add per page; block b's page numbers are pages[b * kPagesPerBlock ...].
+constexpr uint32_t kPageGroups = 512;      // 8 KiB = 2048 tokens
+constexpr uint32_t kPagesPerBlock = 32;    // 65 536 tokens: a block of 64 KiB never needs more (every token yields a byte)
+struct DevSink {
+    uint4* pool;
+    uint32_t n_pages;
+    uint32_t* cursor;    // next free page of the pool
+    uint32_t* my_pages;  // this block's page table
+    uint4* cur = nullptr;
+    uint32_t t0 = 0, t1 = 0, t2 = 0, k = 0;
+    __device__ __forceinline__ bool flush(uint32_t t3) {
+        const uint32_t g = k >> 2;
+        if ((g & (kPageGroups - 1u)) == 0u) {
+            const uint32_t idx = g / kPageGroups;
+            if (idx >= kPagesPerBlock) return false;
+            const uint32_t pg = atomicAdd(cursor, 1u);
+            if (pg >= n_pages) return false;  // the pool is exhausted: the referee takes the block
+            my_pages[idx] = pg;
+            cur = pool + (size_t)pg * kPageGroups;
+        }
+        cur[g & (kPageGroups - 1u)] = make_uint4(t0, t1, t2, t3);
+        return true;
+    }
+    __device__ __forceinline__ bool put(uint32_t t) {
+        const uint32_t ph = k & 3u;
+        t0 = ph == 0u ? t : t0;
+        t1 = ph == 1u ? t : t1;
+        t2 = ph == 2u ? t : t2;
+        bool ok = true;
+        if (ph == 3u) ok = flush(t);
+        ++k;
+        return ok;
+    }
+    __device__ __forceinline__ bool finish() {  // the last, partial group (padded with empty tokens)
+        const uint32_t ph = k & 3u;
+        if (ph == 0u) return true;
+        t1 = ph > 1u ? t1 : 0u;
+        t2 = ph > 2u ? t2 : 0u;
+        const uint32_t keep = k;
+        k |= 3u;  // flush() files the group under k >> 2
+        const bool ok = flush(0u);
+        k = keep;
+        return ok;
+    }
+};
+
 __global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1, (kInflThreads + 255) / 256))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
-                                                                uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed) {
+                                                                uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed,
+                                                                uint4* pool, uint32_t n_pages, uint32_t* pages, uint32_t* ntok) {
     extern __shared__ uint16_t lds_tab[];
     const uint32_t b = blockIdx.x * kInflThreads + threadIdx.x;
     if (b >= n) return;
@@ -95,9 +147,102 @@ __global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1,
     DevMem m{lds_tab + threadIdx.x, reinterpret_cast<uint16_t*>(scr) + lane,
              reinterpret_cast<uint64_t*>(scr + 64u * tec_ginf::kLongSymsPerLane * 2u) + lane};
     const BlockDesc d = desc[b];
+    DevSink sink{pool, n_pages, n_failed + 1, pages + (size_t)b * kPagesPerBlock};
     int rc = tec_ginf::kOk;
-    if (d.isize) rc = tec_ginf::inflate_stream(comp + d.in_off, d.in_len, infl + d.out_off, d.isize, m);
+    if (d.isize) rc = tec_ginf::inflate_stream(comp + d.in_off, d.in_len, infl + d.out_off, d.isize, m, sink);
+    if (rc == tec_ginf::kOk && !sink.finish()) rc = tec_ginf::kTokenOverrun;
+    ntok[b] = rc == tec_ginf::kOk ? sink.k : 0u;
     if (rc != tec_ginf::kOk) failed[atomicAdd(n_failed, 1u)] = b;
+}
+
+// ---- phase 2.  Exact-length copies only: unlike a sequential decoder, a neighbour lane may already have written
+// the bytes behind this match.
+__device__ __forceinline__ uint64_t ld8(const uint8_t* p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void st_tail(uint8_t* q, uint64_t v, uint32_t rem) {  // the low `rem` (< 8) bytes of v
+    if (rem & 4u) {
+        const uint32_t w = (uint32_t)v;
+        memcpy(q, &w, 4);
+        q += 4;
+        v >>= 32;
+    }
+    if (rem & 2u) {
+        const uint16_t w = (uint16_t)v;
+        memcpy(q, &w, 2);
+        q += 2;
+        v >>= 16;
+    }
+    if (rem & 1u) *q = (uint8_t)v;
+}
+__device__ __forceinline__ void copy_match(uint8_t* q, uint32_t len, uint32_t dist) {
+    const uint8_t* p = q - dist;
+    uint32_t k = 0;
+    if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
+        for (; k + 8u <= len; k += 8u) {
+            const uint64_t v = ld8(p + k);
+            memcpy(q + k, &v, 8);
+        }
+        if (k < len) st_tail(q + k, ld8(p + k), len - k);
+    } else {  // a pattern of `dist` bytes: one load, replicated in the register, stored in whole periods
+        uint64_t v = ld8(p);  // (bytes from q on are not written yet: masked off)
+        const uint32_t bits = 8u * dist;
+        v &= (1ull << bits) - 1ull;
+        v |= v << bits;                             // 2 periods (dist <= 4: still inside 64 bits)
+        v |= dist <= 2u ? v << (2u * bits) : 0ull;  // 4 periods
+        v |= dist == 1u ? v << 32 : 0ull;           // 8 periods
+        if (dist == 3u) v |= v << 48;               // (3: 6 bytes from the line above, the rest here)
+        const uint32_t g = dist == 1u ? 8u : (8u / dist) * dist;  // 8 8 6 8 5 6 7
+        for (; k + 8u <= len; k += g) memcpy(q + k, &v, 8);
+        if (k < len) st_tail(q + k, v, len - k);
+    }
+}
+
+// One wave per block.  Tokens [t0, t0 + 64) of a block sit in one page (pages hold 2048 tokens).
+__global__ __launch_bounds__(256) void gresolve_kernel(const BlockDesc* __restrict__ desc, uint32_t n, uint8_t* infl,
+                                                        const uint4* __restrict__ pool, const uint32_t* __restrict__ pages,
+                                                        const uint32_t* __restrict__ ntok) {
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (b >= n) return;
+    const uint32_t T = ntok[b];
+    if (T == 0u) return;  // empty, or refused by phase 1 (the host redoes it)
+    uint8_t* const out = infl + desc[b].out_off;
+    const uint32_t* const pg = pages + (size_t)b * kPagesPerBlock;
+    uint32_t op = 0;
+    for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+        const uint32_t t = t0 + lane;
+        const uint32_t* page = reinterpret_cast<const uint32_t*>(pool + (size_t)pg[t0 / (kPageGroups * 4u)] * kPageGroups);
+        const uint32_t tok = t < T ? page[t & (kPageGroups * 4u - 1u)] : 0u;
+        const uint32_t kind = tok >> 30;
+        const uint32_t nb = tec_ginf::tok_out_bytes(tok);
+        // output positions: inclusive prefix sum over the lanes
+        uint32_t incl = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            incl += lane >= (uint32_t)d ? up : 0u;
+        }
+        const uint32_t dst = op + incl - nb;
+        op += (uint32_t)__shfl((int)incl, 63, 64);
+        uint8_t* const q = out + dst;
+        if (kind == 1u) st_tail(q, tok & 0xFFFFFFu, nb);
+        const uint32_t dist = (tok & 0x7FFFu) + 1u;
+        const uint32_t need_end = dst - dist + (nb < dist ? nb : dist);  // the source bytes that must be final end here
+        unsigned long long pending = __ballot(kind == 2u);
+        while (pending) {  // wave-uniform; the first pending match always qualifies
+            const uint32_t first = (uint32_t)__builtin_ctzll(pending);
+            const uint32_t hwm = (uint32_t)__shfl((int)dst, (int)first, 64);  // everything below is final
+            const bool mine = ((pending >> lane) & 1ull) != 0ull;
+            const bool go = mine && need_end <= hwm;
+            if (go) copy_match(q, nb, dist);
+            pending &= ~__ballot(go);
+#ifdef TEC_GRESOLVE_WAIT
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        }
+    }
 }
 
 // One wave per segment: the smallest offset in the segment at which three consecutive records look
@@ -284,7 +429,7 @@ struct Staged {  // one chunk of compressed blocks: staged through the pinned ri
     DBuf d_comp, d_desc;
     hipEvent_t copied = nullptr;
     // the chunk's inflate launch (its own scratch and failed-block list: two launches are in flight at a time)
-    DBuf d_syms, d_ctl;
+    DBuf d_syms, d_ctl, d_pages, d_ntok;
     hipEvent_t inflate_done = nullptr;
     bool launched = false;
     int buf = 0;  // which of the two inflated-stream buffers it writes
@@ -296,6 +441,7 @@ struct Staged {  // one chunk of compressed blocks: staged through the pinned ri
 // context (allocating and freeing gigabytes of HBM and pinned memory costs more than decoding a small file),
 // the next reader on that context takes them over, tec_destroy frees them.
 struct GbamBuffers {
+    DBuf d_tokpool[2];  // token pages of the launch that writes stream buffer 0 / 1 (phase 1 fills, phase 2 replays)
     DBuf d_infl2[2], d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
     DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
     DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
@@ -326,6 +472,7 @@ struct tec_gbam : GbamBuffers {
     uint32_t chunk_blocks = 256u * kInflThreads < 65536u ? 256u * kInflThreads : 65536u;  // (stream offsets are 32-bit: <= 4 GiB inflated)
     size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size
     int read_threads = 8;
+    int ramp_chunks = 2;  // how many leading chunks of a file are cut short (1, 2 staging pieces)
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
     bool start_known = false;
@@ -360,7 +507,7 @@ int gfail(tec_gbam* g, int code, const std::string& msg) {
 
 // Fills `st` with the owned blocks that start at file offset `off` (at most chunk_bytes / chunk_blocks).
 // epilogue: ignore the range end (blocks needed to complete the last owned record).
-void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t max_blocks) {
+void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t max_blocks, size_t max_bytes = ~size_t(0)) {
     st->desc.clear();
     st->block_off.clear();
     st->bytes = 0;
@@ -389,10 +536,16 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         g->mean_block_bytes = nb ? (double)o / nb : 65536.0;
     }
     const uint64_t expect = (uint64_t)(g->mean_block_bytes * 1.06 * max_blocks) + (1u << 20);
-    const size_t cap_bytes = (size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off);
+    // (max_bytes: the first chunks of a file are kept small, so that the GPU starts inflating after one piece has
+    // been read instead of after a whole chunk's worth)
+    const size_t cap_bytes = (size_t)std::min<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, max_bytes),
+                                                        g->file_size - off);
     hipStream_t cp = g->ctx->s_copy;
     hipError_t e = st->copied ? hipSuccess : hipEventCreateWithFlags(&st->copied, hipEventDisableTiming);
-    if (e == hipSuccess) e = st->d_comp.reserve(cap_bytes + 64);
+    // (room for a full-size chunk from the start: growing the buffer later would mean a hipFree -- a device-wide
+    // synchronisation -- in the middle of the pipeline)
+    if (e == hipSuccess)
+        e = st->d_comp.reserve((size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off) + 64);
     if (e != hipSuccess) {
         st->error = std::string("cannot allocate the chunk's buffer on the GPU: ") + hipGetErrorString(e);
         return;
@@ -663,14 +816,30 @@ int launch_inflate(tec_gbam* g, Staged* st, int buf) {
     const uint32_t waves = (nb + 63u) / 64u;
     G_HIP(st->d_syms.reserve((size_t)std::max(waves, 1u) * kScratchPerWave));
     G_HIP(st->d_ctl.reserve(64 + (size_t)std::max(nb, 1u) * 4));
+    G_HIP(st->d_pages.reserve((size_t)std::max(nb, 1u) * kPagesPerBlock * 4));
+    G_HIP(st->d_ntok.reserve((size_t)std::max(nb, 1u) * 4));
     if (nb) {
-        uint32_t* d_nfailed = st->d_ctl.as<uint32_t>();
+        // token pool: four bytes per symbol-loop iteration.  Twice the inflated size covers a stream of nothing but
+        // single literals twice over; each block leaves at most one page partly filled
+        constexpr size_t page_bytes = (size_t)kPageGroups * 16;
+        const size_t want_pages = (2 * (size_t)st->inflated + page_bytes - 1) / page_bytes + nb;
+        DBuf& pool = g->d_tokpool[buf];
+        if (want_pages * page_bytes > pool.cap) {
+            G_HIP(hipStreamSynchronize(si));  // (phase 2 of the launch before this one on the same stream reads the old pool)
+            G_HIP(pool.reserve(want_pages * page_bytes));
+        }
+        const uint32_t n_pages = (uint32_t)std::min<size_t>(pool.cap / page_bytes, 0xFFFFFFFFu);
+        uint32_t* d_nfailed = st->d_ctl.as<uint32_t>();  // [0] failed blocks, [1] pages drawn from the pool
         G_HIP(hipStreamWaitEvent(si, st->copied, 0));  // the staging thread's copy of this chunk
         G_HIP(hipMemsetAsync(d_nfailed, 0, 64, si));
         hipLaunchKernelGGL(ginflate_kernel, dim3((nb + kInflThreads - 1) / kInflThreads), dim3(kInflThreads),
                            (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, si, st->d_desc.as<BlockDesc>(), nb,
                            st->d_comp.as<uint8_t>(), infl.as<uint8_t>() + kCarryMax, st->d_syms.as<uint16_t>(), d_nfailed,
-                           d_nfailed + 16);
+                           d_nfailed + 16, pool.as<uint4>(), n_pages, st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
+        G_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gresolve_kernel, dim3((nb + 3u) / 4u), dim3(256), 0, si, st->d_desc.as<BlockDesc>(), nb,
+                           infl.as<uint8_t>() + kCarryMax, (const uint4*)pool.as<uint4>(), (const uint32_t*)st->d_pages.as<uint32_t>(),
+                           (const uint32_t*)st->d_ntok.as<uint32_t>());
         G_HIP(hipGetLastError());
     }
     G_HIP(hipEventRecord(st->inflate_done, si));
@@ -927,6 +1096,10 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
         const long nt = atol(e);
         if (nt >= 1 && nt <= 64) g->read_threads = (int)nt;
     }
+    if (const char* e = getenv("TEC_GBAM_RAMP")) {  // (experiments: 0 = every chunk full size)
+        const long k = atol(e);
+        if (k >= 0 && k <= 8) g->ramp_chunks = (int)k;
+    }
     if (const char* e = getenv("TEC_GBAM_CHUNK_BLOCKS")) {
         const long nb = atol(e);
         if (nb >= 1 && nb <= 65536) g->chunk_blocks = (uint32_t)nb;
@@ -988,7 +1161,7 @@ extern "C" const char* tec_gbam_ref_name(const tec_gbam* g, int i) {
 extern "C" uint64_t tec_gbam_file_size(const tec_gbam* g) { return g ? g->file_size : 0; }
 
 static void free_buffers(GbamBuffers* g) {
-    for (DBuf* b : {&g->d_infl2[0], &g->d_infl2[1], &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
+    for (DBuf* b : {&g->d_tokpool[0], &g->d_tokpool[1], &g->d_infl2[0], &g->d_infl2[1], &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
                     &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
                     &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
         b->release();
@@ -1002,6 +1175,8 @@ static void free_buffers(GbamBuffers* g) {
         s.d_desc.release();
         s.d_syms.release();
         s.d_ctl.release();
+        s.d_pages.release();
+        s.d_ntok.release();
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.inflate_done) (void)hipEventDestroy(s.inflate_done);
         s.copied = s.inflate_done = nullptr;
@@ -1079,14 +1254,17 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     std::thread producer([&] {
         int slot = 0;
         uint64_t off = next_off;
-        for (;;) {
+        for (unsigned k = 0;; ++k) {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || ready[slot] == 0; });
                 if (stop) break;
             }
             (void)hipSetDevice(ctx->device);
-            stage_chunk(g, &g->slots[slot], off, false, g->chunk_blocks);
+            // ramp: one staging piece, then two, then whole chunks -- the first inflate launch starts ~10 ms into the
+            // file, and the later, larger chunks are staged while the earlier ones inflate
+            const size_t ramp = k < (unsigned)g->ramp_chunks ? g->piece_bytes << k : ~size_t(0);
+            stage_chunk(g, &g->slots[slot], off, false, g->chunk_blocks, ramp);
             const bool last = g->slots[slot].last || !g->slots[slot].error.empty();
             off = g->slots[slot].next_off;
             {

@@ -2,28 +2,29 @@
 // (gbam.hip), written so that the very same source also compiles for the host, where the CPU test
 // suite runs it against zlib on every stream shape zlib can produce.
 //
-// Why a different decoder from inflate_fast.h: on the GPU one lane inflates one BGZF block, what limits
-// the number of lanes per CU is table memory, and what limits a lane's speed is the number of
-// global-memory round trips on its critical path (on gfx9 loads and stores retire in order through one
-// counter, so a load that follows a store waits for that store).  Hence:
+// Inflation is split in two (gbam.hip has the kernels):
+//   phase 1  (this file, inflate_stream)  one LANE per BGZF block walks the bit stream -- the part of DEFLATE that
+//            is serial by nature -- and turns it into a stream of 32-bit TOKENS: up to three literal bytes, or one
+//            match {length, distance}, or a run of stored bytes.  It writes nothing to the inflated stream and
+//            never reads it back: its only memory traffic is the 8-byte input refills and one 16-byte token store
+//            per four symbols.  (When the lane also performed the copies, every match was a load that had to wait
+//            for the lane's own earlier stores -- gfx9 retires loads and stores in order through one counter -- and
+//            a wave spent ten times its instruction time per symbol.)
+//   phase 2  (resolve_tokens below for the host; gresolve_kernel on the device)  one WAVE per block replays the
+//            tokens: 64 tokens at a time, output positions by a wave prefix sum, literals stored at once, matches
+//            copied in rounds -- a match goes as soon as its source bytes lie below the first match still pending.
+//
+// Why a different decoder from inflate_fast.h: what limits the number of lanes per CU is table memory, hence
 //   * tables are small and 16-bit, in LDS: literal/length 7-bit first level (128 entries), distance
 //     5-bit (32) = 320 bytes per lane -> 512 lanes (eight waves, two per SIMD) per CU in exactly the
-//     160 KiB of LDS; the second wave of a SIMD issues while the first waits for memory.  Measured
-//     ladder (48 M-record file): 9-bit level, 128 lanes 0.56 s; 8-bit, 192 lanes 0.47 s; 8-bit, 256
-//     lanes 0.42 s -- and, once two launches overlap, 0.258 s against 0.228 s for this layout;
+//     160 KiB of LDS; the second wave of a SIMD issues while the first waits for memory;
 //   * the code lengths of a dynamic block go to the lane's global scratch as they are decoded (sixteen
-//     nibbles per 64-bit store; stores do not stall the lane) and come back in symbol order for the two
-//     passes of the table builder; the distance lengths stay in two registers;
+//     nibbles per 64-bit store) and come back in symbol order for the two passes of the table builder; the
+//     distance lengths stay in two registers;
 //   * codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit,
 //     from per-length counts packed in registers; only their symbols live in global scratch;
 //   * base values and extra-bit counts of length / distance symbols are computed arithmetically;
-//   * literals are stored as they are decoded; matches are copied eight bytes per round trip (a run of
-//     one byte needs no loads at all);
 //   * input arrives as 8-byte loads issued one step ahead of their use.
-// Two other formulations were measured on the MI355X and lost to this one: routing all
-// output through a 16-byte register accumulator, and a flat one-byte-per-step state machine with all
-// memory traffic at common sync points -- both removed the memory waits and both paid for it with
-// three to four times the instructions per symbol.
 //
 // Replaces, on the device, the BGZF inflation that the reference gets from pysam / htslib
 // (te_count/te_count.py:65,190,351); follows RFC 1951 only.
@@ -58,7 +59,50 @@ constexpr uint32_t kInPad = 16;                                       // readabl
 
 // Reasons a block is handed back to the host's referee decoder (zlib / inflate_fast.h).
 enum : int { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadCode = 4, kBadSymbol = 5, kBadDistance = 6,
-             kOutputOverrun = 7, kInputOverrun = 8, kShortOutput = 9 };
+             kOutputOverrun = 7, kInputOverrun = 8, kShortOutput = 9, kTokenOverrun = 10 };
+
+// ---- tokens: what phase 1 hands to phase 2, one 32-bit word per symbol-loop iteration
+//   bits 31:30  kind   0 nothing (padding), 1 literals, 2 match, 3 skip (bytes of a stored block, already in place)
+//   literals    bits 25:24 count (1..3), bits 23:0 the bytes, first one lowest
+//   match       bits 22:15 length - 3 (0..255), bits 14:0 distance - 1
+//   skip        bits 15:0 byte count
+constexpr uint32_t kTokLit = 1u << 30, kTokMatch = 2u << 30, kTokSkip = 3u << 30;
+TEC_HD uint32_t tok_kind(uint32_t t) { return t >> 30; }
+TEC_HD uint32_t tok_out_bytes(uint32_t t) {
+    const uint32_t k = t >> 30;
+    return k == 1u ? (t >> 24) & 3u : (k == 2u ? ((t >> 15) & 0xFFu) + 3u : (k == 3u ? t & 0xFFFFu : 0u));
+}
+
+// Host sink: a growing array.  (The device sink, gbam.hip, packs four tokens per 16-byte store into pages
+// drawn from a pool.)  put() returns false when the sink is full: the block is then handed to the referee.
+struct VectorSink {
+    uint32_t* tok;
+    uint32_t cap, n = 0;
+    bool put(uint32_t t) {
+        if (n >= cap) return false;
+        tok[n++] = t;
+        return true;
+    }
+};
+
+// Phase 2 on the host: replays a token stream into out[0, out_len).  Returns false if the tokens do not describe
+// exactly out_len bytes (phase 1 has checked distances and lengths; this is a second line of defence).
+inline bool resolve_tokens(const uint32_t* tok, uint32_t n, uint8_t* out, uint32_t out_len) {
+    uint32_t op = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t t = tok[i], k = t >> 30, nb = tok_out_bytes(t);
+        if (out_len - op < nb) return false;
+        if (k == 1u) {
+            for (uint32_t j = 0; j < nb; ++j) out[op + j] = (uint8_t)(t >> (8u * j));
+        } else if (k == 2u) {
+            const uint32_t dist = (t & 0x7FFFu) + 1u;
+            if (dist > op) return false;
+            for (uint32_t j = 0; j < nb; ++j) out[op + j] = out[op + j - dist];
+        }
+        op += nb;
+    }
+    return op == out_len;
+}
 
 // Per-lane memory.  The device instantiation keeps `tab` in LDS and the long-code symbols in global
 // memory; the host instantiation uses plain arrays.
@@ -278,10 +322,12 @@ TEC_HD uint32_t decode_long(const Mem& m, BitReader& br, uint32_t root, uint32_t
     return 0xFFFFu;
 }
 
-// Inflates the raw DEFLATE stream in[0, in_len) into exactly out_len bytes.  kOk, or the reason the
-// block must be redone by the referee.  `in` must be readable up to in + in_len + kInPad.
-template <class Mem>
-TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, Mem& m) {
+// Phase 1: turns the raw DEFLATE stream in[0, in_len), which inflates to exactly out_len bytes, into tokens
+// (sink.put).  Only the bytes of STORED blocks are written to `out` (at their final place: no later token reads
+// anything but final bytes).  kOk, or the reason the block must be redone by the referee.  `in` must be readable
+// up to in + in_len + kInPad.
+template <class Mem, class Sink>
+TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, Mem& m, Sink& sink) {
     BitReader br;
     br.in = in;
     br.in_end = in + in_len;
@@ -313,6 +359,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             }
             for (; k < len; ++k) q[k] = src[k];
             op += len;
+            if (len && !sink.put(kTokSkip | len)) return kTokenOverrun;
             br.start(src + len);
             continue;
         }
@@ -412,17 +459,21 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             }
             if (s < 256u) {
                 if (op >= out_len) return kOutputOverrun;
-                out[op++] = (uint8_t)s;
+                uint32_t lit = s, nlit = 1;
+                ++op;
                 // up to two more literals from the bits already in the buffer (>= 18 after any first code, and a
                 // first-level code has at most kLitRoot bits): lanes in a literal run advance three symbols in the
-                // time a neighbour lane spends on one match (five more, with a refill in between, was slower)
+                // time a neighbour lane spends on one match
 #pragma unroll
                 for (int extra = 0; extra < 2; ++extra) {
                     const uint32_t e2 = m.tab(br.peek(kLitRoot));
                     if ((e2 & 15u) == 0u || (e2 >> 4) >= 256u || op >= out_len) break;
                     br.drop(e2 & 15u);
-                    out[op++] = (uint8_t)(e2 >> 4);
+                    lit |= (e2 >> 4) << (8u * nlit);
+                    ++nlit;
+                    ++op;
                 }
+                if (!sink.put(kTokLit | (nlit << 24) | lit)) return kTokenOverrun;
                 continue;
             }
             if (s == 256u) break;
@@ -449,53 +500,8 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (dist > op) return kBadDistance;
             if (out_len - op < length) return kOutputOverrun;
             if (br.far_overrun()) return kInputOverrun;
-            uint8_t* q = out + op;
-            const uint8_t* p = q - dist;
             op += length;
-            if (out_len - op >= 8u) {
-                // Whole 8-byte groups only: the last group may run up to seven bytes past the match -- into bytes
-                // of this block that are not produced yet and will be overwritten when they are.  (The tail of a
-                // match, byte by byte, was up to fourteen dependent one-byte round trips.)
-                if (dist >= 32u) {
-                    // four groups per round trip: on gfx9 a load waits for every older store of the lane, so a
-                    // group-by-group copy is one store + load round trip (microseconds under load) per 8 bytes, and
-                    // the wave waits for its lane with the longest match.  32 source bytes are never bytes the same
-                    // batch writes.
-                    for (uint32_t k = 0; k < length; k += 32u) {
-                        uint64_t v0, v1, v2, v3;
-                        memcpy(&v0, p + k, 8);
-                        memcpy(&v1, p + k + 8, 8);
-                        memcpy(&v2, p + k + 16, 8);
-                        memcpy(&v3, p + k + 24, 8);
-                        memcpy(q + k, &v0, 8);
-                        if (k + 8u < length) memcpy(q + k + 8, &v1, 8);
-                        if (k + 16u < length) memcpy(q + k + 16, &v2, 8);
-                        if (k + 24u < length) memcpy(q + k + 24, &v3, 8);
-                    }
-                } else if (dist >= 8u) {  // eight source bytes are never bytes the same group writes
-                    for (uint32_t k = 0; k < length; k += 8u) {
-                        uint64_t v;
-                        memcpy(&v, p + k, 8);
-                        memcpy(q + k, &v, 8);
-                    }
-                } else {  // a pattern of `dist` bytes: one load, replicated in the register, stored in whole periods
-                    uint64_t v;
-                    memcpy(&v, p, 8);  // (bytes from q on are not written yet: masked off)
-                    const uint32_t bits = 8u * dist;
-                    v &= (1ull << bits) - 1ull;
-                    v |= v << bits;                               // 2 periods (dist <= 4: still inside 64 bits)
-                    v |= dist <= 2u ? v << (2u * bits) : 0ull;    // 4 periods
-                    v |= dist == 1u ? v << 32 : 0ull;             // 8 periods
-                    if (dist == 3u) v |= v << 48;                 // (3: 6 bytes from the line above, the rest here)
-                    const uint32_t g = dist == 1u ? 8u : (8u / dist) * dist;  // 8 8 6 8 5 6 7
-                    for (uint32_t k = 0; k < length; k += g) memcpy(q + k, &v, 8);
-                }
-            } else if (dist == 1u) {  // the last bytes of the block: exact writes
-                const uint8_t c = *p;
-                for (uint32_t k = 0; k < length; ++k) q[k] = c;
-            } else {
-                for (uint32_t k = 0; k < length; ++k) q[k] = p[k];
-            }
+            if (!sink.put(kTokMatch | ((length - 3u) << 15) | (dist - 1u))) return kTokenOverrun;
         }
         if (br.far_overrun()) return kInputOverrun;
     }
