@@ -4,10 +4,12 @@ the host-side mirror of the reference's `measureTE` interface."""
 
 import os as _os
 
-# The on-GPU BAM decoder keeps two inflate launches in flight on two streams; with ROCm's default of four hardware
-# queues per process two of the library's streams can land on one queue and run one after the other.  Read by the HIP
-# runtime when it initialises, so it has to be in the environment before the first GPU call of the process.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# The on-GPU BAM decoder keeps the inflate launches of several chunks in flight, each on a stream of its own; with four
+# hardware queues per process (ROCm's default) the library's streams share queues and those launches run one after the
+# other.  Raised to eight unless the caller asked for more.  Read by the HIP runtime when it initialises, so it has to be
+# in the environment before the first GPU call of the process.
+if int(_os.environ.get('GPU_MAX_HW_QUEUES') or 0) < 8:
+    _os.environ['GPU_MAX_HW_QUEUES'] = '8'
 
 from . import _lib  # noqa: E402
 from .index import FlatIndex  # noqa: E402

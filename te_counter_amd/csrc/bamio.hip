@@ -450,7 +450,7 @@ extern "C" int tec_inflate_raw(const uint8_t* in, uint64_t in_len, uint8_t* out,
         std::unique_ptr<tec_ginf::HostMem> m(new tec_ginf::HostMem);
         memset(m.get(), 0x77, sizeof(tec_ginf::HostMem));
         // phase 1 (the lane's code) into a token array, phase 2 replayed sequentially
-        std::vector<uint32_t> tok((size_t)out_len + 4096);
+        std::vector<uint32_t> tok((size_t)out_len / 3 + out_len / 128 + 16);
         tec_ginf::VectorSink sink{tok.data(), (uint32_t)tok.size()};
         if (tec_ginf::inflate_stream(padded.data(), (uint32_t)in_len, out, (uint32_t)out_len, *m, sink) != tec_ginf::kOk) return TEC_EINVAL;
         return tec_ginf::resolve_tokens(tok.data(), sink.n, out, (uint32_t)out_len) ? TEC_OK : TEC_EINVAL;

@@ -25,9 +25,11 @@ extern "C" const char* tec_last_error(const tec_ctx* ctx) { return ctx ? ctx->er
 extern "C" int tec_create(int device_id, tec_ctx** out) {
     if (!out) return tec_fail(nullptr, TEC_EINVAL, "tec_create: out is NULL");
     *out = nullptr;
-    // two inflate launches of the BAM decoder run side by side on two streams: with the default of four hardware queues
-    // per process two of this library's streams may share one (effective only if HIP is not initialised yet)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // the BAM decoder keeps the inflate launches of several chunks in flight, each on a stream of its own: with four
+    // hardware queues per process (HIP's default) this library's streams share queues and those launches run one after
+    // the other.  Raised to eight unless the caller asked for more (effective only if HIP is not initialised yet)
+    const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+    if (!hwq || atoi(hwq) < 8) setenv("GPU_MAX_HW_QUEUES", "8", 1);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)

@@ -6,12 +6,12 @@
 // into a ring of pinned buffers, walks the BGZF headers and sends the blocks to HBM on the copy stream
 // (stage_chunk).  Everything else runs on the MI355X:
 //
-//   ginflate_kernel     phase 1 of the inflation: one LANE per BGZF block decodes the Huffman bit stream into 32-bit
-//                       tokens (ginflate.h: 16-bit tables in LDS, 320 B per lane -> 512 lanes per CU), four tokens per
-//                       16-byte store into 8 KiB pages drawn from a pool; the lane never touches the inflated stream
-//   gresolve_kernel     phase 2: one WAVE per block replays the tokens, 64 at a time: positions by a wave prefix sum,
-//                       literals stored at once, matches copied in rounds (a match goes as soon as its source lies
-//                       below the first match still pending).  A block that phase 1 refuses is redone by the host's
+//   ginflate_kernel     phase 1 of the inflation: one LANE per BGZF block decodes the Huffman bit stream (ginflate.h:
+//                       16-bit tables in LDS, 320 B per lane -> 512 lanes per CU), stores literal bytes at their final
+//                       place and turns every match into a 32-bit token, four tokens per 16-byte store into 8 KiB pages
+//                       drawn from a pool; the lane never reads the inflated stream
+//   gresolve_kernel     phase 2: one WAVE per block replays the matches, 64 at a time: positions by a wave prefix sum,
+//                       copies in rounds (a match goes as soon as its source lies below the first match still pending).  A block that phase 1 refuses is redone by the host's
 //                       referee decoder (inflate_fast.h, then zlib) and patched in
 //   seg_guess_kernel    the inflated stream is cut into 64 KiB segments; one wave per segment looks for
 //                       the first offset at which a chain of BAM records plausibly starts (bamscan.h)
@@ -27,9 +27,10 @@
 // and the units go straight to the count kernel (tec_bulk_submit_device) or the single-cell ingest
 // (tec_sc_submit_device) without ever visiting host memory.
 //
-// Pipeline (run_decode): a chunk is <= 65 536 blocks (32-bit stream offsets).  Chunk k + 1's inflate is launched
-// -- on its own stream, into the other of two stream buffers -- before chunk k is consumed, so two launches share
-// the chip while the host steps and row kernels of chunk k run; the staging thread is a chunk or two ahead.
+// Pipeline (run_decode): a chunk is 16 384 blocks, chunk k lives in slot k % kDepth (its own compressed bytes, stream
+// buffer, token pool and stream).  The staging thread launches a chunk's inflate kernels the moment its bytes are on
+// their way to HBM, so up to kDepth - 1 launches share the chip while the host steps and row kernels of an earlier
+// chunk run on the compute stream.
 //
 // Multi-GPU: a reader owns a byte range of the file (include/tecount.h, tec_bam_open_range has the
 // rules); the first record of a range that does not start at 0 is a guess that the caller verifies
@@ -58,11 +59,9 @@ constexpr uint32_t kMaxRecPerSeg = kSeg / 36u + 2u;  // a record is at least 36 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 const bool kTrace = getenv("TEC_GBAM_TRACE") != nullptr;  // staging-thread phase times on stderr
 constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one chunk to the next
-#ifndef TEC_GINF_THREADS
-#define TEC_GINF_THREADS 512
-#endif
+constexpr int kStreams = 5;              // inflate streams (slot i launches on stream i % kStreams)
+constexpr int kDepth = 8;                // chunks in flight: being staged, inflating or being consumed (chunk k lives in slot k % kDepth)
 constexpr size_t kScratchPerWave = 64u * (tec_ginf::kLongSymsPerLane * 2u + tec_ginf::kLenWords * 8u);  // global scratch of the inflate kernel
-constexpr int kInflThreads = TEC_GINF_THREADS;        // lanes per workgroup of the inflate kernel = lanes per CU (LDS bound)
 constexpr uint32_t kFlagFilter = TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP;
 
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -72,18 +71,19 @@ struct BlockDesc {
     uint32_t out_off, isize;  // inflated bytes inside the chunk's inflated stream
 };
 
-// ---- per-lane memory of the inflate kernel: tables in LDS, lane-interleaved (entry i of lane L at
-// u16 index i * 512 + L: same-i accesses of a wave are consecutive, random-i accesses always land
-// in the lane pair's own bank); the symbols of long codes and the code lengths of the block being
+// ---- per-lane memory of the inflate kernel: tables in LDS, lane-interleaved (entry i of lane L of a workgroup of
+// kThreads lanes at u16 index i * kThreads + L: same-i accesses of a wave are consecutive, random-i accesses always
+// land in the lane pair's own bank); the symbols of long codes and the code lengths of the block being
 // set up in global memory, interleaved per wave
+template <int kThreads>
 struct DevMem {
     uint16_t* t;
     uint16_t* s;
     uint64_t* w;  // code lengths of the dynamic block being set up, 16 per word, interleaved per wave like s
     __device__ __forceinline__ uint64_t lenw(uint32_t k) const { return w[k * 64u]; }
     __device__ __forceinline__ void set_lenw(uint32_t k, uint64_t v) { w[k * 64u] = v; }
-    __device__ __forceinline__ uint32_t tab(uint32_t i) const { return t[i * kInflThreads]; }
-    __device__ __forceinline__ void set_tab(uint32_t i, uint32_t v) { t[i * kInflThreads] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t tab(uint32_t i) const { return t[i * kThreads]; }
+    __device__ __forceinline__ void set_tab(uint32_t i, uint32_t v) { t[i * kThreads] = (uint16_t)v; }
     __device__ __forceinline__ uint32_t sym(uint32_t i) const { return s[i * 64u]; }
     __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
 };
@@ -91,7 +91,7 @@ struct DevMem {
 // ---- token pages.  A block's tokens go, four per 16-byte group, into pages of kPageGroups groups that its lane draws
 // from a pool with one atomic add per page; block b's page numbers are pages[b * kPagesPerBlock ...].
 constexpr uint32_t kPageGroups = 512;      // 8 KiB = 2048 tokens
-constexpr uint32_t kPagesPerBlock = 32;    // 65 536 tokens: a block of 64 KiB never needs more (every token yields a byte)
+constexpr uint32_t kPagesPerBlock = 12;    // 24 576 tokens: a block of 64 KiB has at most 65 536 / 3 + 65 536 / 128 + 2
 struct DevSink {
     uint4* pool;
     uint32_t n_pages;
@@ -135,16 +135,17 @@ struct DevSink {
     }
 };
 
-__global__ __launch_bounds__(kInflThreads) __attribute__((amdgpu_waves_per_eu(1, (kInflThreads + 255) / 256))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
                                                                 uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed,
                                                                 uint4* pool, uint32_t n_pages, uint32_t* pages, uint32_t* ntok) {
     extern __shared__ uint16_t lds_tab[];
-    const uint32_t b = blockIdx.x * kInflThreads + threadIdx.x;
+    const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
     if (b >= n) return;
     const size_t wave = b >> 6, lane = b & 63u;
     uint8_t* const scr = reinterpret_cast<uint8_t*>(syms_scr) + wave * kScratchPerWave;
-    DevMem m{lds_tab + threadIdx.x, reinterpret_cast<uint16_t*>(scr) + lane,
+    DevMem<kThreads> m{lds_tab + threadIdx.x, reinterpret_cast<uint16_t*>(scr) + lane,
              reinterpret_cast<uint64_t*>(scr + 64u * tec_ginf::kLongSymsPerLane * 2u) + lane};
     const BlockDesc d = desc[b];
     DevSink sink{pool, n_pages, n_failed + 1, pages + (size_t)b * kPagesPerBlock};
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(256) void gresolve_kernel(const BlockDesc* __restri
         const uint32_t t = t0 + lane;
         const uint32_t* page = reinterpret_cast<const uint32_t*>(pool + (size_t)pg[t0 / (kPageGroups * 4u)] * kPageGroups);
         const uint32_t tok = t < T ? page[t & (kPageGroups * 4u - 1u)] : 0u;
-        const uint32_t kind = tok >> 30;
-        const uint32_t nb = tec_ginf::tok_out_bytes(tok);
+        const uint32_t len = tec_ginf::tok_match_len(tok);
+        const uint32_t nb = tec_ginf::tok_before(tok) + len;  // bytes in place in front of the match, then the match
         // output positions: inclusive prefix sum over the lanes
         uint32_t incl = nb;
 #pragma unroll
@@ -224,23 +225,19 @@ __global__ __launch_bounds__(256) void gresolve_kernel(const BlockDesc* __restri
             const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
             incl += lane >= (uint32_t)d ? up : 0u;
         }
-        const uint32_t dst = op + incl - nb;
+        const uint32_t dst = op + incl - len;  // where the match starts
         op += (uint32_t)__shfl((int)incl, 63, 64);
         uint8_t* const q = out + dst;
-        if (kind == 1u) st_tail(q, tok & 0xFFFFFFu, nb);
         const uint32_t dist = (tok & 0x7FFFu) + 1u;
-        const uint32_t need_end = dst - dist + (nb < dist ? nb : dist);  // the source bytes that must be final end here
-        unsigned long long pending = __ballot(kind == 2u);
+        const uint32_t need_end = dst - dist + (len < dist ? len : dist);  // the source bytes that must be final end here
+        unsigned long long pending = __ballot(len != 0u);
         while (pending) {  // wave-uniform; the first pending match always qualifies
             const uint32_t first = (uint32_t)__builtin_ctzll(pending);
             const uint32_t hwm = (uint32_t)__shfl((int)dst, (int)first, 64);  // everything below is final
             const bool mine = ((pending >> lane) & 1ull) != 0ull;
             const bool go = mine && need_end <= hwm;
-            if (go) copy_match(q, nb, dist);
+            if (go) copy_match(q, len, dist);
             pending &= ~__ballot(go);
-#ifdef TEC_GRESOLVE_WAIT
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         }
     }
 }
@@ -430,7 +427,7 @@ struct Staged {  // one chunk of compressed blocks: staged through the pinned ri
     hipEvent_t copied = nullptr;
     // the chunk's inflate launch (its own scratch and failed-block list: two launches are in flight at a time)
     DBuf d_syms, d_ctl, d_pages, d_ntok;
-    hipEvent_t inflate_done = nullptr;
+    hipEvent_t inflate_done = nullptr;  // completion of the chunk's phase-2 kernel
     bool launched = false;
     int buf = 0;  // which of the two inflated-stream buffers it writes
 };
@@ -441,15 +438,18 @@ struct Staged {  // one chunk of compressed blocks: staged through the pinned ri
 // context (allocating and freeing gigabytes of HBM and pinned memory costs more than decoding a small file),
 // the next reader on that context takes them over, tec_destroy frees them.
 struct GbamBuffers {
-    DBuf d_tokpool[2];  // token pages of the launch that writes stream buffer 0 / 1 (phase 1 fills, phase 2 replays)
-    DBuf d_infl2[2], d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
+    DBuf d_tokpool[kDepth];  // token pages of the chunk in slot i (phase 1 fills, phase 2 replays)
+    DBuf d_infl2[kDepth], d_ctl, d_guess, d_count, d_land, d_offs, d_segbase, d_reflen, d_tidmap, d_carry;
     DBuf r_chrom, r_pos, r_end, r_flag, r_mapq, r_qkey, r_cb, r_ub, r_tf;  // record arrays
     DBuf u_chrom, u_p1, u_p2, u_flag, u_mapq;                                // PE units
     DBuf d_flags;
     uint64_t r_cap = 0, u_cap = 0;
-    Staged slots[3];
-    hipStream_t s_infl2[2] = {nullptr, nullptr};  // one inflate stream per stream buffer: the two launches in flight overlap
-    hipEvent_t buf_free[2] = {nullptr, nullptr};  // the stream buffer's last reader has finished
+    Staged slots[kDepth];                 // slot i owns stream buffer i and token pool i
+    // Chunk k's two inflate kernels go to stream k % kStreams, phase 2 in order behind phase 1: the launches of up to
+    // kStreams chunks overlap when the streams sit on different hardware queues.  A process has GPU_MAX_HW_QUEUES of them
+    // (HIP's default: four) for all its streams and which one a stream gets is not ours to choose: with four, two of these
+    // streams share a queue and their 30 ms launches run back to back; tec_create asks for eight before HIP initialises.
+    hipStream_t s_infl[kStreams] = {};
     int cur_buf = 0;                      // buffer of the chunk being consumed (the carry sits in front of its stream)
     Piece pieces[3];  // one being walked / copied, one being read, one whose copy to HBM drains
     int next_piece = 0;
@@ -467,12 +467,14 @@ struct tec_gbam : GbamBuffers {
     uint64_t first_data_off = 0;     // file offset of the first BGZF block this reader stages
     uint64_t hdr_block_off = 0;      // range 0: block that holds the first record ...
     uint32_t hdr_inblock = 0;        // ... and its offset inside that block's inflated bytes
-    // one chunk = one launch of the inflate kernel: 65536 blocks = 128 workgroups of 512 lanes; two launches in flight fill the chip
+    // one chunk = one launch of each inflate kernel.  Phase 1 is one lane per block, so a launch takes a block's serial decode
+    // time (~30 ms) whether it holds 16 384 blocks or 65 536: chunks are SMALL and up to kDepth of them are in flight -- the
+    // first launch starts one staging piece into the file, and what is left to do once the last byte is staged is one small chunk
     size_t chunk_bytes = 2047u << 20;
-    uint32_t chunk_blocks = 256u * kInflThreads < 65536u ? 256u * kInflThreads : 65536u;  // (stream offsets are 32-bit: <= 4 GiB inflated)
+    uint32_t chunk_blocks = 16384;  // 32 workgroups of 512 lanes; (stream offsets are 32-bit: <= 4 GiB inflated)
     size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size
     int read_threads = 8;
-    int ramp_chunks = 2;  // how many leading chunks of a file are cut short (1, 2 staging pieces)
+    int infl_lanes = 256;  // lanes per workgroup of the inflate kernel (320 bytes of LDS each)
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
     bool start_known = false;
@@ -507,7 +509,7 @@ int gfail(tec_gbam* g, int code, const std::string& msg) {
 
 // Fills `st` with the owned blocks that start at file offset `off` (at most chunk_bytes / chunk_blocks).
 // epilogue: ignore the range end (blocks needed to complete the last owned record).
-void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t max_blocks, size_t max_bytes = ~size_t(0)) {
+void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t max_blocks) {
     st->desc.clear();
     st->block_off.clear();
     st->bytes = 0;
@@ -536,16 +538,10 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         g->mean_block_bytes = nb ? (double)o / nb : 65536.0;
     }
     const uint64_t expect = (uint64_t)(g->mean_block_bytes * 1.06 * max_blocks) + (1u << 20);
-    // (max_bytes: the first chunks of a file are kept small, so that the GPU starts inflating after one piece has
-    // been read instead of after a whole chunk's worth)
-    const size_t cap_bytes = (size_t)std::min<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, max_bytes),
-                                                        g->file_size - off);
+    const size_t cap_bytes = (size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off);
     hipStream_t cp = g->ctx->s_copy;
     hipError_t e = st->copied ? hipSuccess : hipEventCreateWithFlags(&st->copied, hipEventDisableTiming);
-    // (room for a full-size chunk from the start: growing the buffer later would mean a hipFree -- a device-wide
-    // synchronisation -- in the middle of the pipeline)
-    if (e == hipSuccess)
-        e = st->d_comp.reserve((size_t)std::min<uint64_t>(std::min<uint64_t>(g->chunk_bytes, expect) + 65536 + 64, g->file_size - off) + 64);
+    if (e == hipSuccess) e = st->d_comp.reserve(cap_bytes + 64);
     if (e != hipSuccess) {
         st->error = std::string("cannot allocate the chunk's buffer on the GPU: ") + hipGetErrorString(e);
         return;
@@ -794,18 +790,19 @@ int pair_and_count(tec_gbam* g, RunState* rs, const RunArgs& a, uint64_t first, 
     return TEC_OK;
 }
 
-// Starts the inflate kernel of a staged chunk on the inflate stream, into stream buffer `buf`.  Two launches are
-// in flight at a time (one workgroup holds a CU's whole LDS; a launch of 65 536 blocks covers half the chip), so that
-// while the host and the row kernels deal with chunk k the chip keeps inflating chunk k + 1.
-int launch_inflate(tec_gbam* g, Staged* st, int buf) {
+// Both inflate kernels of a staged chunk into stream buffer `buf`, on inflate stream `lane_stream` (staging thread; the epilogue: calling thread).  Stream
+// buffer `buf` must be free (the caller knows: its last reader synchronised); the chunk's copy to HBM is waited for on the device.
+int launch_inflate(tec_gbam* g, Staged* st, int buf, int lane_stream) {
     tec_ctx* ctx = g->ctx;
     st->buf = buf;
     st->launched = true;
     const uint32_t nb = (uint32_t)st->desc.size();
-    if (!g->s_infl2[buf]) G_HIP(hipStreamCreateWithFlags(&g->s_infl2[buf], hipStreamNonBlocking));
-    hipStream_t si = g->s_infl2[buf];
-    if (!st->inflate_done) G_HIP(hipEventCreateWithFlags(&st->inflate_done, hipEventDisableTiming));
-    if (g->buf_free[buf]) G_HIP(hipStreamWaitEvent(si, g->buf_free[buf], 0));  // its last reader (rows of chunk k - 2)
+    hipStream_t si = g->s_infl[lane_stream];
+    if (!si) {
+        G_HIP(hipStreamCreateWithFlags(&g->s_infl[lane_stream], hipStreamNonBlocking));
+        si = g->s_infl[lane_stream];
+    }
+    if (!st->inflate_done) G_HIP(hipEventCreate(&st->inflate_done));
     DBuf& infl = g->d_infl2[buf];
     if (kCarryMax + st->inflated + 256 > infl.cap) {
         // (growing copies the carry area: nothing may be in flight on either side)
@@ -818,30 +815,30 @@ int launch_inflate(tec_gbam* g, Staged* st, int buf) {
     G_HIP(st->d_ctl.reserve(64 + (size_t)std::max(nb, 1u) * 4));
     G_HIP(st->d_pages.reserve((size_t)std::max(nb, 1u) * kPagesPerBlock * 4));
     G_HIP(st->d_ntok.reserve((size_t)std::max(nb, 1u) * 4));
-    if (nb) {
-        // token pool: four bytes per symbol-loop iteration.  Twice the inflated size covers a stream of nothing but
-        // single literals twice over; each block leaves at most one page partly filled
-        constexpr size_t page_bytes = (size_t)kPageGroups * 16;
-        const size_t want_pages = (2 * (size_t)st->inflated + page_bytes - 1) / page_bytes + nb;
-        DBuf& pool = g->d_tokpool[buf];
-        if (want_pages * page_bytes > pool.cap) {
-            G_HIP(hipStreamSynchronize(si));  // (phase 2 of the launch before this one on the same stream reads the old pool)
-            G_HIP(pool.reserve(want_pages * page_bytes));
-        }
-        const uint32_t n_pages = (uint32_t)std::min<size_t>(pool.cap / page_bytes, 0xFFFFFFFFu);
-        uint32_t* d_nfailed = st->d_ctl.as<uint32_t>();  // [0] failed blocks, [1] pages drawn from the pool
-        G_HIP(hipStreamWaitEvent(si, st->copied, 0));  // the staging thread's copy of this chunk
-        G_HIP(hipMemsetAsync(d_nfailed, 0, 64, si));
-        hipLaunchKernelGGL(ginflate_kernel, dim3((nb + kInflThreads - 1) / kInflThreads), dim3(kInflThreads),
-                           (size_t)kInflThreads * tec_ginf::kEntriesPerLane * 2, si, st->d_desc.as<BlockDesc>(), nb,
-                           st->d_comp.as<uint8_t>(), infl.as<uint8_t>() + kCarryMax, st->d_syms.as<uint16_t>(), d_nfailed,
-                           d_nfailed + 16, pool.as<uint4>(), n_pages, st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
-        G_HIP(hipGetLastError());
-        hipLaunchKernelGGL(gresolve_kernel, dim3((nb + 3u) / 4u), dim3(256), 0, si, st->d_desc.as<BlockDesc>(), nb,
-                           infl.as<uint8_t>() + kCarryMax, (const uint4*)pool.as<uint4>(), (const uint32_t*)st->d_pages.as<uint32_t>(),
-                           (const uint32_t*)st->d_ntok.as<uint32_t>());
-        G_HIP(hipGetLastError());
-    }
+    if (!nb) return TEC_OK;
+    // token pool: four bytes per match.  A pool of 3/4 of the inflated size holds any stream whose matches average
+    // 5.4 bytes or more (BAM payloads average 8 to 30); each block leaves at most one page partly filled.  A block
+    // that finds the pool empty is refused and redone by the host's referee -- slow, never wrong
+    constexpr size_t page_bytes = (size_t)kPageGroups * 16;
+    const size_t want_pages = ((size_t)st->inflated / 4 * 3 + page_bytes - 1) / page_bytes + (size_t)nb;
+    DBuf& pool = g->d_tokpool[buf];
+    if (want_pages * page_bytes > pool.cap) G_HIP(pool.reserve(want_pages * page_bytes));  // (the slot's previous chunk is done)
+    const uint32_t n_pages = (uint32_t)std::min<size_t>(pool.cap / page_bytes, 0xFFFFFFFFu);
+    uint32_t* d_nfailed = st->d_ctl.as<uint32_t>();  // [0] failed blocks, [1] pages drawn from the pool
+    G_HIP(hipMemsetAsync(d_nfailed, 0, 64, si));
+    G_HIP(hipStreamWaitEvent(si, st->copied, 0));  // the staging thread's copy of this chunk
+    auto p1 = [&](auto kernel, uint32_t lanes) {
+        kernel<<<(nb + lanes - 1) / lanes, lanes, (size_t)lanes * tec_ginf::kEntriesPerLane * 2, si>>>(
+            st->d_desc.as<BlockDesc>(), nb, st->d_comp.as<uint8_t>(), infl.as<uint8_t>() + kCarryMax, st->d_syms.as<uint16_t>(), d_nfailed,
+            d_nfailed + 16, pool.as<uint4>(), n_pages, st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
+    };
+    if (g->infl_lanes == 128) p1(ginflate_kernel<128>, 128);
+    else if (g->infl_lanes == 512) p1(ginflate_kernel<512>, 512);
+    else p1(ginflate_kernel<256>, 256);
+    G_HIP(hipGetLastError());
+    gresolve_kernel<<<(nb + 3u) / 4u, 256, 0, si>>>(st->d_desc.as<BlockDesc>(), nb, infl.as<uint8_t>() + kCarryMax, pool.as<uint4>(),
+                                                   st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
+    G_HIP(hipGetLastError());
     G_HIP(hipEventRecord(st->inflate_done, si));
     return TEC_OK;
 }
@@ -860,8 +857,8 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     res->tail = total;
     if (total == 0) return TEC_OK;
     // ---- the inflated stream (the kernel was started ahead of time for all but the first chunk and the epilogue)
-    if (!st->launched) {
-        int rc = launch_inflate(g, st, g->cur_buf);
+    if (!st->launched) {  // (the epilogue; chunks of the main loop were launched by the staging thread)
+        int rc = launch_inflate(g, st, g->cur_buf, 0);
         if (rc) return rc;
     }
     g->cur_buf = st->buf;
@@ -870,15 +867,17 @@ int process_chunk(tec_gbam* g, Staged* st, const RunArgs& a, RunState* rs, bool 
     uint8_t* d_stream_base = g->d_infl2[st->buf].as<uint8_t>() + kCarryMax;  // inflated bytes of this chunk start here
     uint8_t* d_stream = d_stream_base - carry;                               // stream offset 0
     double t0 = now_s();
-    G_HIP(hipEventSynchronize(st->inflate_done));
+    if (nb) G_HIP(hipEventSynchronize(st->inflate_done));
     if (nb) {
         uint32_t n_failed = 0;
         G_HIP(hipMemcpy(&n_failed, d_nfailed, 4, hipMemcpyDeviceToHost));
+        if (n_failed > nb) return gfail(g, TEC_EHIP, "the inflate kernel reported more failed blocks than the chunk holds");
         if (n_failed) {  // the referee: the host's decoder (and zlib behind it) has the last word
             std::vector<uint32_t> bad(n_failed);
             G_HIP(hipMemcpy(bad.data(), d_failed, (size_t)n_failed * 4, hipMemcpyDeviceToHost));
             std::vector<uint8_t> tmp(65536);
             for (uint32_t b : bad) {
+                if (b >= nb) return gfail(g, TEC_EHIP, "the inflate kernel reported a block that is not in the chunk");
                 const BlockDesc& d = st->desc[b];
                 std::vector<uint8_t> body(d.in_len + 16, 0);  // (the pinned ring has moved on: read the block again)
                 if (pread(g->fd, body.data(), d.in_len, (off_t)(st->file_off + d.in_off)) != (ssize_t)d.in_len ||
@@ -1096,10 +1095,7 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
         const long nt = atol(e);
         if (nt >= 1 && nt <= 64) g->read_threads = (int)nt;
     }
-    if (const char* e = getenv("TEC_GBAM_RAMP")) {  // (experiments: 0 = every chunk full size)
-        const long k = atol(e);
-        if (k >= 0 && k <= 8) g->ramp_chunks = (int)k;
-    }
+    if (const char* e = getenv("TEC_GBAM_LANES")) g->infl_lanes = atoi(e);
     if (const char* e = getenv("TEC_GBAM_CHUNK_BLOCKS")) {
         const long nb = atol(e);
         if (nb >= 1 && nb <= 65536) g->chunk_blocks = (uint32_t)nb;
@@ -1133,9 +1129,12 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = g->d_reflen.reserve(std::max<size_t>(1, (size_t)n_ref) * 4);
     if (e == hipSuccess && n_ref) e = hipMemcpy(g->d_reflen.p, g->ref_lens.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ginflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kInflThreads * (int)tec_ginf::kEntriesPerLane * 2);
+    if (e == hipSuccess && g->infl_lanes == 512)  // (more than 64 KiB of dynamic LDS has to be asked for)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                512 * (int)tec_ginf::kEntriesPerLane * 2);
+    if (e == hipSuccess && g->infl_lanes == 256)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                256 * (int)tec_ginf::kEntriesPerLane * 2);
     if (e != hipSuccess) {
         close(g->fd);
         g->d_reflen.release();
@@ -1161,7 +1160,9 @@ extern "C" const char* tec_gbam_ref_name(const tec_gbam* g, int i) {
 extern "C" uint64_t tec_gbam_file_size(const tec_gbam* g) { return g ? g->file_size : 0; }
 
 static void free_buffers(GbamBuffers* g) {
-    for (DBuf* b : {&g->d_tokpool[0], &g->d_tokpool[1], &g->d_infl2[0], &g->d_infl2[1], &g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
+    for (auto& b : g->d_tokpool) b.release();
+    for (auto& b : g->d_infl2) b.release();
+    for (DBuf* b : {&g->d_ctl, &g->d_guess, &g->d_count, &g->d_land, &g->d_offs,
                     &g->d_segbase, &g->d_flags, &g->d_reflen, &g->d_tidmap, &g->d_carry, &g->r_chrom, &g->r_pos, &g->r_end, &g->r_flag,
                     &g->r_mapq, &g->r_qkey, &g->r_cb, &g->r_ub, &g->r_tf, &g->u_chrom, &g->u_p1, &g->u_p2, &g->u_flag, &g->u_mapq})
         b->release();
@@ -1181,13 +1182,9 @@ static void free_buffers(GbamBuffers* g) {
         if (s.inflate_done) (void)hipEventDestroy(s.inflate_done);
         s.copied = s.inflate_done = nullptr;
     }
-    for (auto& e : g->buf_free) {
-        if (e) (void)hipEventDestroy(e);
-        e = nullptr;
-    }
-    for (auto& q : g->s_infl2) {
-        if (q) (void)hipStreamDestroy(q);
-        q = nullptr;
+    for (hipStream_t& si : g->s_infl) {
+        if (si) (void)hipStreamDestroy(si);
+        si = nullptr;
     }
 }
 
@@ -1205,8 +1202,8 @@ extern "C" void tec_gbam_close(tec_gbam* g) {
         (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->s_compute);
         (void)hipStreamSynchronize(g->ctx->s_copy);  // a staged chunk that was never processed may still be copying
-        for (auto q : g->s_infl2)
-            if (q) (void)hipStreamSynchronize(q);  // ... or inflating
+        for (hipStream_t si : g->s_infl)
+            if (si) (void)hipStreamSynchronize(si);  // ... or inflating
     }
     if (g->ctx && !g->ctx->gbam_cache) {
         g->ctx->gbam_cache = new GbamBuffers(static_cast<GbamBuffers&>(*g));  // parked for the next reader
@@ -1235,46 +1232,72 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     rs.d_first_noend = flags.as<unsigned long long>();
     rs.d_first_mismatch = rs.d_first_noend + 1;
     rs.d_bad_layout = reinterpret_cast<uint32_t*>(rs.d_first_noend + 2);
-    G_HIP(g->d_infl2[0].reserve(kCarryMax + 256));
-    G_HIP(g->d_infl2[1].reserve(kCarryMax + 256));
-    for (auto& e : g->buf_free)
-        if (!e) G_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g->cur_buf = 0;
     g->deferred = a.deferred;
     g->n_resident = 0;
     g->n_records = 0;
+    // Stream buffers at their final size BEFORE the pipeline starts: a chunk holds at most chunk_blocks blocks of at
+    // most 64 KiB, and the number of chunks follows from the file size and the mean block size (a 4 MiB probe).  The
+    // staging thread launches the inflates, this thread copies record tails into the fronts of the same buffers:
+    // neither may see a buffer move.  (Should an estimate fall short, the staging thread waits until this thread has
+    // caught up and grows the buffer then.)
+    {
+        const uint64_t range_bytes = std::min<uint64_t>(g->range_end, g->file_size) - std::min<uint64_t>(g->first_data_off, g->file_size);
+        if (g->mean_block_bytes <= 0 && range_bytes) {
+            std::vector<uint8_t> probe((size_t)std::min<uint64_t>(4u << 20, range_bytes) + 32, 0);
+            const ssize_t k = pread(g->fd, probe.data(), probe.size() - 32, (off_t)g->first_data_off);
+            size_t o = 0, bsize, body_off, body_len;
+            uint32_t isize, nb = 0;
+            while (k > 0 && tec_bgzf_parse(probe.data(), (size_t)k, o, &bsize, &body_off, &body_len, &isize)) {
+                o += bsize;
+                ++nb;
+            }
+            g->mean_block_bytes = nb ? (double)o / nb : 65536.0;
+        }
+        const uint64_t est_blocks = (uint64_t)((double)range_bytes / std::max(g->mean_block_bytes, 28.0) * 1.1) + 16;
+        const uint64_t n_chunks = (est_blocks + g->chunk_blocks - 1) / g->chunk_blocks;
+        const int n_full = (int)std::min<uint64_t>(kDepth, n_chunks + 1);  // (+ 1: the epilogue reads into the buffer after the last chunk's)
+        const size_t cap = kCarryMax + (size_t)std::min<uint64_t>(g->chunk_blocks, est_blocks) * 65536 + 256;
+        for (int i = 0; i < kDepth; ++i) G_HIP(g->d_infl2[i].reserve(i < n_full ? cap : kCarryMax + 256));
+    }
 
-    // ---- producer
+    // ---- the staging thread: chunk k -> slot k % kDepth: pread + header walk + H2D (stage_chunk), then -- at once, from this
+    // thread -- the chunk's two inflate kernels.  The GPU starts on the file as soon as the first chunk is staged and never waits
+    // for the consumer's host steps.
     std::mutex mu;
     std::condition_variable cv;
-    int ready[3] = {0, 0, 0};  // 0 free, 1 staged
+    int ready[kDepth] = {};  // 0 free, 1 staged and launched
+    uint64_t processed = 0;  // chunks this thread is done with (rows extracted, tail moved on, compute stream drained)
     bool stop = false;
     uint64_t next_off = g->first_data_off;
-    bool producer_done = false;
     std::thread producer([&] {
-        int slot = 0;
         uint64_t off = next_off;
-        for (unsigned k = 0;; ++k) {
+        for (uint64_t k = 0;; ++k) {
+            const int slot = (int)(k % kDepth);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || ready[slot] == 0; });
                 if (stop) break;
             }
             (void)hipSetDevice(ctx->device);
-            // ramp: one staging piece, then two, then whole chunks -- the first inflate launch starts ~10 ms into the
-            // file, and the later, larger chunks are staged while the earlier ones inflate
-            const size_t ramp = k < (unsigned)g->ramp_chunks ? g->piece_bytes << k : ~size_t(0);
-            stage_chunk(g, &g->slots[slot], off, false, g->chunk_blocks, ramp);
-            const bool last = g->slots[slot].last || !g->slots[slot].error.empty();
-            off = g->slots[slot].next_off;
+            Staged* st = &g->slots[slot];
+            stage_chunk(g, st, off, false, g->chunk_blocks);
+            if (st->error.empty() && !st->desc.empty()) {
+                if (kCarryMax + st->inflated + 256 > g->d_infl2[slot].cap) {  // (an estimate fell short: see above)
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || processed == k; });
+                    if (stop) break;
+                }
+                if (launch_inflate(g, st, slot, (int)(k % kStreams)) != TEC_OK) st->error = "inflate launch failed: " + g->err;
+            }
+            const bool last = st->last || !st->error.empty();
+            off = st->next_off;
             {
                 std::lock_guard<std::mutex> lk(mu);
                 ready[slot] = 1;
-                if (last) producer_done = true;
             }
             cv.notify_all();
             if (last) break;
-            slot = (slot + 1) % 3;
         }
     });
     auto finish_producer = [&] {
@@ -1290,10 +1313,9 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     int slot = 0;
     uint64_t end_off = g->first_data_off;  // file offset behind the last staged owned block
     bool at_eof = false;
-    Staged* last_st = nullptr;
-    ChunkResult last_res;
     bool first_token_pending = !g->start_known;
-    for (;;) {
+    for (uint64_t k = 0;; ++k) {
+        slot = (int)(k % kDepth);
         {
             const double tw = now_s();
             std::unique_lock<std::mutex> lk(mu);
@@ -1304,24 +1326,6 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
         if (!st->error.empty()) {
             rc = gfail(g, TEC_EINVAL, st->error);
             break;
-        }
-        if (!st->launched) {  // the first chunk
-            rc = launch_inflate(g, st, g->cur_buf);
-            if (rc) break;
-        }
-        const int nslot = (slot + 1) % 3;
-        if (!st->last) {  // the next chunk's inflate starts before this chunk is dealt with: two launches in flight
-            {
-                const double tw = now_s();
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return ready[nslot] == 1; });
-                g->t_stage_wait += now_s() - tw;
-            }
-            Staged* nst = &g->slots[nslot];
-            if (nst->error.empty()) {
-                rc = launch_inflate(g, nst, st->buf ^ 1);
-                if (rc) break;
-            }
         }
         ChunkResult res;
         rc = process_chunk(g, st, a, &rs, false, &res);
@@ -1344,9 +1348,9 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             rc = gfail(g, TEC_EOVERFLOW, "a BAM record larger than 64 MiB is not supported");
             break;
         }
-        const int nbuf = st->buf ^ 1;  // where the next chunk (or the epilogue) has its stream
+        const int nbuf = (slot + 1) % kDepth;  // where the next chunk (or the epilogue) has its stream
         if (new_carry) {
-            const uint8_t* src = g->d_infl2[st->buf].as<uint8_t>() + kCarryMax - res.carry_in + res.tail;
+            const uint8_t* src = g->d_infl2[slot].as<uint8_t>() + kCarryMax - res.carry_in + res.tail;
             uint8_t* dst = g->d_infl2[nbuf].as<uint8_t>() + kCarryMax - new_carry;
             hipError_t e = hipMemcpyAsync(dst, src, new_carry, hipMemcpyDeviceToDevice, cs);
             if (e != hipSuccess) {
@@ -1355,9 +1359,11 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             }
         }
         {
-            hipError_t e = hipEventRecord(g->buf_free[st->buf], cs);  // rows are extracted, the tail has moved on
+            // rows are extracted, the tail has moved on: once the compute stream has drained, the slot's buffers may be written
+            // again (the staging thread launches the next phase 1 into them without any device-side wait)
+            hipError_t e = hipStreamSynchronize(cs);
             if (e != hipSuccess) {
-                rc = gfail(g, TEC_EHIP, std::string("event record failed: ") + hipGetErrorString(e));
+                rc = gfail(g, TEC_EHIP, std::string("stream synchronisation failed: ") + hipGetErrorString(e));
                 break;
             }
         }
@@ -1366,25 +1372,21 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
         end_off = st->next_off;
         at_eof = st->at_eof;
         const bool last = st->last;
-        last_st = st;
-        last_res = res;
-        if (last) break;
         {
             std::lock_guard<std::mutex> lk(mu);
-            ready[slot] = 0;
+            if (!last) ready[slot] = 0;
+            processed = k + 1;
         }
         cv.notify_all();
-        slot = nslot;
+        if (last) break;
     }
     finish_producer();
     if (rc) {
         return rc;
     }
-    (void)last_st;
-    (void)last_res;
 
     // ---- the epilogue: a record that starts in owned bytes and ends beyond the range; the end token
-    Staged* ep = &g->slots[(slot + 1) % 3];
+    Staged* ep = &g->slots[(slot + 1) % kDepth];
     uint64_t off = end_off;
     bool token_done = false;
     if (rs.carry_len && g->start_known) {

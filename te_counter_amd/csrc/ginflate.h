@@ -4,15 +4,15 @@
 //
 // Inflation is split in two (gbam.hip has the kernels):
 //   phase 1  (this file, inflate_stream)  one LANE per BGZF block walks the bit stream -- the part of DEFLATE that
-//            is serial by nature -- and turns it into a stream of 32-bit TOKENS: up to three literal bytes, or one
-//            match {length, distance}, or a run of stored bytes.  It writes nothing to the inflated stream and
-//            never reads it back: its only memory traffic is the 8-byte input refills and one 16-byte token store
-//            per four symbols.  (When the lane also performed the copies, every match was a load that had to wait
-//            for the lane's own earlier stores -- gfx9 retires loads and stores in order through one counter -- and
-//            a wave spent ten times its instruction time per symbol.)
+//            is serial by nature.  Literal bytes (and the bytes of stored blocks) go straight to their final place in
+//            the inflated stream; every MATCH becomes a 32-bit token {literals in front of it, length, distance}.
+//            The lane never reads the inflated stream back: its loads are the 8-byte input refills only.  (When the
+//            lane also performed the copies, every match was a load that had to wait for the lane's own earlier
+//            stores -- gfx9 retires loads and stores in order through one counter -- and a wave spent ten times its
+//            instruction time per symbol.)
 //   phase 2  (resolve_tokens below for the host; gresolve_kernel on the device)  one WAVE per block replays the
-//            tokens: 64 tokens at a time, output positions by a wave prefix sum, literals stored at once, matches
-//            copied in rounds -- a match goes as soon as its source bytes lie below the first match still pending.
+//            matches: 64 tokens at a time, output positions by a wave prefix sum, copies in rounds -- a match goes
+//            as soon as its source bytes lie below the first match still pending.
 //
 // Why a different decoder from inflate_fast.h: what limits the number of lanes per CU is table memory, hence
 //   * tables are small and 16-bit, in LDS: literal/length 7-bit first level (128 entries), distance
@@ -61,17 +61,16 @@ constexpr uint32_t kInPad = 16;                                       // readabl
 enum : int { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadCode = 4, kBadSymbol = 5, kBadDistance = 6,
              kOutputOverrun = 7, kInputOverrun = 8, kShortOutput = 9, kTokenOverrun = 10 };
 
-// ---- tokens: what phase 1 hands to phase 2, one 32-bit word per symbol-loop iteration
-//   bits 31:30  kind   0 nothing (padding), 1 literals, 2 match, 3 skip (bytes of a stored block, already in place)
-//   literals    bits 25:24 count (1..3), bits 23:0 the bytes, first one lowest
-//   match       bits 22:15 length - 3 (0..255), bits 14:0 distance - 1
-//   skip        bits 15:0 byte count
-constexpr uint32_t kTokLit = 1u << 30, kTokMatch = 2u << 30, kTokSkip = 3u << 30;
-TEC_HD uint32_t tok_kind(uint32_t t) { return t >> 30; }
-TEC_HD uint32_t tok_out_bytes(uint32_t t) {
-    const uint32_t k = t >> 30;
-    return k == 1u ? (t >> 24) & 3u : (k == 2u ? ((t >> 15) & 0xFFu) + 3u : (k == 3u ? t & 0xFFFFu : 0u));
-}
+// ---- tokens: what phase 1 hands to phase 2, one 32-bit word per match
+//   bits 31:30  kind   0 nothing (padding), 2 match, 3 skip
+//   match       bits 29:23 bytes already in place in front of the match (literals, stored bytes: 0..127),
+//               bits 22:15 length - 3 (0..255), bits 14:0 distance - 1
+//   skip        bits 19:0 bytes already in place (a run longer than 127, or the tail behind the last match)
+// A block of n bytes has at most n / 3 + n / 128 + 2 tokens.
+constexpr uint32_t kTokMatch = 2u << 30, kTokSkip = 3u << 30;
+constexpr uint32_t kTokMaxBefore = 127u, kTokMaxSkip = 0xFFFFFu;
+TEC_HD uint32_t tok_before(uint32_t t) { return (t >> 30) == 2u ? (t >> 23) & 127u : ((t >> 30) == 3u ? t & kTokMaxSkip : 0u); }
+TEC_HD uint32_t tok_match_len(uint32_t t) { return (t >> 30) == 2u ? ((t >> 15) & 0xFFu) + 3u : 0u; }
 
 // Host sink: a growing array.  (The device sink, gbam.hip, packs four tokens per 16-byte store into pages
 // drawn from a pool.)  put() returns false when the sink is full: the block is then handed to the referee.
@@ -85,21 +84,21 @@ struct VectorSink {
     }
 };
 
-// Phase 2 on the host: replays a token stream into out[0, out_len).  Returns false if the tokens do not describe
-// exactly out_len bytes (phase 1 has checked distances and lengths; this is a second line of defence).
+// Phase 2 on the host: replays the matches into out[0, out_len), whose literal bytes are in place.  Returns false if
+// the tokens do not describe exactly out_len bytes (phase 1 has checked distances and lengths; this is a second line
+// of defence).
 inline bool resolve_tokens(const uint32_t* tok, uint32_t n, uint8_t* out, uint32_t out_len) {
     uint32_t op = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t t = tok[i], k = t >> 30, nb = tok_out_bytes(t);
-        if (out_len - op < nb) return false;
-        if (k == 1u) {
-            for (uint32_t j = 0; j < nb; ++j) out[op + j] = (uint8_t)(t >> (8u * j));
-        } else if (k == 2u) {
+        const uint32_t t = tok[i], before = tok_before(t), len = tok_match_len(t);
+        if (out_len - op < before || out_len - op - before < len) return false;
+        op += before;
+        if (len) {
             const uint32_t dist = (t & 0x7FFFu) + 1u;
             if (dist > op) return false;
-            for (uint32_t j = 0; j < nb; ++j) out[op + j] = out[op + j - dist];
+            for (uint32_t j = 0; j < len; ++j) out[op + j] = out[op + j - dist];
+            op += len;
         }
-        op += nb;
     }
     return op == out_len;
 }
@@ -322,10 +321,9 @@ TEC_HD uint32_t decode_long(const Mem& m, BitReader& br, uint32_t root, uint32_t
     return 0xFFFFu;
 }
 
-// Phase 1: turns the raw DEFLATE stream in[0, in_len), which inflates to exactly out_len bytes, into tokens
-// (sink.put).  Only the bytes of STORED blocks are written to `out` (at their final place: no later token reads
-// anything but final bytes).  kOk, or the reason the block must be redone by the referee.  `in` must be readable
-// up to in + in_len + kInPad.
+// Phase 1: walks the raw DEFLATE stream in[0, in_len), which inflates to exactly out_len bytes: literal and stored
+// bytes are written to `out` at their final place, matches become tokens (sink.put).  kOk, or the reason the block
+// must be redone by the referee.  `in` must be readable up to in + in_len + kInPad.
 template <class Mem, class Sink>
 TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, Mem& m, Sink& sink) {
     BitReader br;
@@ -333,6 +331,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
     br.in_end = in + in_len;
     br.start(in);
     uint32_t op = 0;
+    uint32_t run = 0;  // bytes in place since the last token
     bool last = false;
     while (!last) {
         br.refill();
@@ -359,7 +358,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             }
             for (; k < len; ++k) q[k] = src[k];
             op += len;
-            if (len && !sink.put(kTokSkip | len)) return kTokenOverrun;
+            run += len;
             br.start(src + len);
             continue;
         }
@@ -459,8 +458,8 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             }
             if (s < 256u) {
                 if (op >= out_len) return kOutputOverrun;
-                uint32_t lit = s, nlit = 1;
-                ++op;
+                out[op++] = (uint8_t)s;
+                ++run;
                 // up to two more literals from the bits already in the buffer (>= 18 after any first code, and a
                 // first-level code has at most kLitRoot bits): lanes in a literal run advance three symbols in the
                 // time a neighbour lane spends on one match
@@ -469,11 +468,9 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                     const uint32_t e2 = m.tab(br.peek(kLitRoot));
                     if ((e2 & 15u) == 0u || (e2 >> 4) >= 256u || op >= out_len) break;
                     br.drop(e2 & 15u);
-                    lit |= (e2 >> 4) << (8u * nlit);
-                    ++nlit;
-                    ++op;
+                    out[op++] = (uint8_t)(e2 >> 4);
+                    ++run;
                 }
-                if (!sink.put(kTokLit | (nlit << 24) | lit)) return kTokenOverrun;
                 continue;
             }
             if (s == 256u) break;
@@ -501,11 +498,17 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (out_len - op < length) return kOutputOverrun;
             if (br.far_overrun()) return kInputOverrun;
             op += length;
-            if (!sink.put(kTokMatch | ((length - 3u) << 15) | (dist - 1u))) return kTokenOverrun;
+            if (run > kTokMaxBefore) {  // a long run of bytes in place gets a token of its own
+                if (!sink.put(kTokSkip | run)) return kTokenOverrun;
+                run = 0;
+            }
+            if (!sink.put(kTokMatch | (run << 23) | ((length - 3u) << 15) | (dist - 1u))) return kTokenOverrun;
+            run = 0;
         }
         if (br.far_overrun()) return kInputOverrun;
     }
     if (br.overrun()) return kInputOverrun;
+    if (run && !sink.put(kTokSkip | run)) return kTokenOverrun;  // (run <= out_len <= 65 536)
     return op == out_len ? kOk : kShortOutput;
 }
 
