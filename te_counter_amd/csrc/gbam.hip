@@ -84,54 +84,43 @@ struct DevMem {
     __device__ __forceinline__ void set_lenw(uint32_t k, uint64_t v) { w[k * 64u] = v; }
     __device__ __forceinline__ uint32_t tab(uint32_t i) const { return t[i * kThreads]; }
     __device__ __forceinline__ void set_tab(uint32_t i, uint32_t v) { t[i * kThreads] = (uint16_t)v; }
-    __device__ __forceinline__ uint32_t sym(uint32_t i) const { return s[i * 64u]; }
-    __device__ __forceinline__ void set_sym(uint32_t i, uint32_t v) { s[i * 64u] = (uint16_t)v; }
+    // sorted symbols of the long codes: the first kLongLds ranks behind the table in LDS, the others in global scratch
+    __device__ __forceinline__ uint32_t lsym(uint32_t i) const {
+        return i < tec_ginf::kLongLds ? t[(tec_ginf::kLitEntries + i) * kThreads] : s[i * 64u];
+    }
+    __device__ __forceinline__ uint32_t lsym_near(uint32_t i) const { return t[(tec_ginf::kLitEntries + i) * kThreads]; }
+    __device__ __forceinline__ void set_lsym(uint32_t i, uint32_t v) {
+        if (i < tec_ginf::kLongLds)
+            t[(tec_ginf::kLitEntries + i) * kThreads] = (uint16_t)v;
+        else
+            s[i * 64u] = (uint16_t)v;
+    }
 };
 
-// ---- token pages.  A block's tokens go, four per 16-byte group, into pages of kPageGroups groups that its lane draws
-// from a pool with one atomic add per page; block b's page numbers are pages[b * kPagesPerBlock ...].
-constexpr uint32_t kPageGroups = 512;      // 8 KiB = 2048 tokens
-constexpr uint32_t kPagesPerBlock = 12;    // 24 576 tokens: a block of 64 KiB has at most 65 536 / 3 + 65 536 / 128 + 2
+// ---- token pages.  A block's tokens go into pages of kPageTokens that its lane draws from a pool with one atomic add
+// per page; block b's page numbers are pages[b * kPagesPerBlock ...].
+constexpr uint32_t kPageTokens = 2048;     // 8 KiB
+constexpr uint32_t kPagesPerBlock = 12;    // 24 576 tokens: a block of 64 KiB has at most 65 536 / 3 + 65 536 / 256 + 2
 struct DevSink {
-    uint4* pool;
+    uint32_t* pool;
     uint32_t n_pages;
     uint32_t* cursor;    // next free page of the pool
     uint32_t* my_pages;  // this block's page table
-    uint4* cur = nullptr;
-    uint32_t t0 = 0, t1 = 0, t2 = 0, k = 0;
-    __device__ __forceinline__ bool flush(uint32_t t3) {
-        const uint32_t g = k >> 2;
-        if ((g & (kPageGroups - 1u)) == 0u) {
-            const uint32_t idx = g / kPageGroups;
+    uint32_t* cur = nullptr;
+    uint32_t k = 0;
+    __device__ __forceinline__ bool put(uint32_t t) {
+        const uint32_t i = k & (kPageTokens - 1u);
+        if (i == 0u) {
+            const uint32_t idx = k / kPageTokens;
             if (idx >= kPagesPerBlock) return false;
             const uint32_t pg = atomicAdd(cursor, 1u);
             if (pg >= n_pages) return false;  // the pool is exhausted: the referee takes the block
             my_pages[idx] = pg;
-            cur = pool + (size_t)pg * kPageGroups;
+            cur = pool + (size_t)pg * kPageTokens;
         }
-        cur[g & (kPageGroups - 1u)] = make_uint4(t0, t1, t2, t3);
-        return true;
-    }
-    __device__ __forceinline__ bool put(uint32_t t) {
-        const uint32_t ph = k & 3u;
-        t0 = ph == 0u ? t : t0;
-        t1 = ph == 1u ? t : t1;
-        t2 = ph == 2u ? t : t2;
-        bool ok = true;
-        if (ph == 3u) ok = flush(t);
+        cur[i] = t;
         ++k;
-        return ok;
-    }
-    __device__ __forceinline__ bool finish() {  // the last, partial group (padded with empty tokens)
-        const uint32_t ph = k & 3u;
-        if (ph == 0u) return true;
-        t1 = ph > 1u ? t1 : 0u;
-        t2 = ph > 2u ? t2 : 0u;
-        const uint32_t keep = k;
-        k |= 3u;  // flush() files the group under k >> 2
-        const bool ok = flush(0u);
-        k = keep;
-        return ok;
+        return true;
     }
 };
 
@@ -139,7 +128,7 @@ template <int kThreads>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void ginflate_kernel(const BlockDesc* __restrict__ desc, uint32_t n,
                                                                 const uint8_t* __restrict__ comp, uint8_t* infl,
                                                                 uint16_t* syms_scr, uint32_t* n_failed, uint32_t* failed,
-                                                                uint4* pool, uint32_t n_pages, uint32_t* pages, uint32_t* ntok) {
+                                                                uint32_t* pool, uint32_t n_pages, uint32_t* pages, uint32_t* ntok) {
     extern __shared__ uint16_t lds_tab[];
     const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
     if (b >= n) return;
@@ -151,7 +140,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
     DevSink sink{pool, n_pages, n_failed + 1, pages + (size_t)b * kPagesPerBlock};
     int rc = tec_ginf::kOk;
     if (d.isize) rc = tec_ginf::inflate_stream(comp + d.in_off, d.in_len, infl + d.out_off, d.isize, m, sink);
-    if (rc == tec_ginf::kOk && !sink.finish()) rc = tec_ginf::kTokenOverrun;
     ntok[b] = rc == tec_ginf::kOk ? sink.k : 0u;
     if (rc != tec_ginf::kOk) failed[atomicAdd(n_failed, 1u)] = b;
 }
@@ -203,7 +191,7 @@ __device__ __forceinline__ void copy_match(uint8_t* q, uint32_t len, uint32_t di
 
 // One wave per block.  Tokens [t0, t0 + 64) of a block sit in one page (pages hold 2048 tokens).
 __global__ __launch_bounds__(256) void gresolve_kernel(const BlockDesc* __restrict__ desc, uint32_t n, uint8_t* infl,
-                                                        const uint4* __restrict__ pool, const uint32_t* __restrict__ pages,
+                                                        const uint32_t* __restrict__ pool, const uint32_t* __restrict__ pages,
                                                         const uint32_t* __restrict__ ntok) {
     const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (b >= n) return;
@@ -214,8 +202,8 @@ __global__ __launch_bounds__(256) void gresolve_kernel(const BlockDesc* __restri
     uint32_t op = 0;
     for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
         const uint32_t t = t0 + lane;
-        const uint32_t* page = reinterpret_cast<const uint32_t*>(pool + (size_t)pg[t0 / (kPageGroups * 4u)] * kPageGroups);
-        const uint32_t tok = t < T ? page[t & (kPageGroups * 4u - 1u)] : 0u;
+        const uint32_t* page = pool + (size_t)pg[t0 / kPageTokens] * kPageTokens;
+        const uint32_t tok = t < T ? page[t & (kPageTokens - 1u)] : 0u;
         const uint32_t len = tec_ginf::tok_match_len(tok);
         const uint32_t nb = tec_ginf::tok_before(tok) + len;  // bytes in place in front of the match, then the match
         // output positions: inclusive prefix sum over the lanes
@@ -474,7 +462,7 @@ struct tec_gbam : GbamBuffers {
     uint32_t chunk_blocks = 16384;  // 32 workgroups of 512 lanes; (stream offsets are 32-bit: <= 4 GiB inflated)
     size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size
     int read_threads = 8;
-    int infl_lanes = 256;  // lanes per workgroup of the inflate kernel (320 bytes of LDS each)
+    int infl_lanes = 256;  // lanes per workgroup of the inflate kernel (640 bytes of LDS each)
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
     bool start_known = false;
@@ -819,7 +807,7 @@ int launch_inflate(tec_gbam* g, Staged* st, int buf, int lane_stream) {
     // token pool: four bytes per match.  A pool of 3/4 of the inflated size holds any stream whose matches average
     // 5.4 bytes or more (BAM payloads average 8 to 30); each block leaves at most one page partly filled.  A block
     // that finds the pool empty is refused and redone by the host's referee -- slow, never wrong
-    constexpr size_t page_bytes = (size_t)kPageGroups * 16;
+    constexpr size_t page_bytes = (size_t)kPageTokens * 4;
     const size_t want_pages = ((size_t)st->inflated / 4 * 3 + page_bytes - 1) / page_bytes + (size_t)nb;
     DBuf& pool = g->d_tokpool[buf];
     if (want_pages * page_bytes > pool.cap) G_HIP(pool.reserve(want_pages * page_bytes));  // (the slot's previous chunk is done)
@@ -830,13 +818,12 @@ int launch_inflate(tec_gbam* g, Staged* st, int buf, int lane_stream) {
     auto p1 = [&](auto kernel, uint32_t lanes) {
         kernel<<<(nb + lanes - 1) / lanes, lanes, (size_t)lanes * tec_ginf::kEntriesPerLane * 2, si>>>(
             st->d_desc.as<BlockDesc>(), nb, st->d_comp.as<uint8_t>(), infl.as<uint8_t>() + kCarryMax, st->d_syms.as<uint16_t>(), d_nfailed,
-            d_nfailed + 16, pool.as<uint4>(), n_pages, st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
+            d_nfailed + 16, pool.as<uint32_t>(), n_pages, st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
     };
     if (g->infl_lanes == 128) p1(ginflate_kernel<128>, 128);
-    else if (g->infl_lanes == 512) p1(ginflate_kernel<512>, 512);
     else p1(ginflate_kernel<256>, 256);
     G_HIP(hipGetLastError());
-    gresolve_kernel<<<(nb + 3u) / 4u, 256, 0, si>>>(st->d_desc.as<BlockDesc>(), nb, infl.as<uint8_t>() + kCarryMax, pool.as<uint4>(),
+    gresolve_kernel<<<(nb + 3u) / 4u, 256, 0, si>>>(st->d_desc.as<BlockDesc>(), nb, infl.as<uint8_t>() + kCarryMax, pool.as<uint32_t>(),
                                                    st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
     G_HIP(hipGetLastError());
     G_HIP(hipEventRecord(st->inflate_done, si));
@@ -1129,10 +1116,10 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = g->d_reflen.reserve(std::max<size_t>(1, (size_t)n_ref) * 4);
     if (e == hipSuccess && n_ref) e = hipMemcpy(g->d_reflen.p, g->ref_lens.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && g->infl_lanes == 512)  // (more than 64 KiB of dynamic LDS has to be asked for)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                512 * (int)tec_ginf::kEntriesPerLane * 2);
-    if (e == hipSuccess && g->infl_lanes == 256)
+    if (e == hipSuccess)  // (more than 64 KiB of dynamic LDS has to be asked for)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                128 * (int)tec_ginf::kEntriesPerLane * 2);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 256 * (int)tec_ginf::kEntriesPerLane * 2);
     if (e != hipSuccess) {

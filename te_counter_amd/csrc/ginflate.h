@@ -5,26 +5,27 @@
 // Inflation is split in two (gbam.hip has the kernels):
 //   phase 1  (this file, inflate_stream)  one LANE per BGZF block walks the bit stream -- the part of DEFLATE that
 //            is serial by nature.  Literal bytes (and the bytes of stored blocks) go straight to their final place in
-//            the inflated stream; every MATCH becomes a 32-bit token {literals in front of it, length, distance}.
-//            The lane never reads the inflated stream back: its loads are the 8-byte input refills only.  (When the
-//            lane also performed the copies, every match was a load that had to wait for the lane's own earlier
-//            stores -- gfx9 retires loads and stores in order through one counter -- and a wave spent ten times its
-//            instruction time per symbol.)
+//            the inflated stream; every MATCH becomes a 32-bit token {bytes in place in front of it, length, distance}.
+//            The lane never reads the inflated stream back: its loads are the 8-byte input refills only.
 //   phase 2  (resolve_tokens below for the host; gresolve_kernel on the device)  one WAVE per block replays the
 //            matches: 64 tokens at a time, output positions by a wave prefix sum, copies in rounds -- a match goes
 //            as soon as its source bytes lie below the first match still pending.
 //
-// Why a different decoder from inflate_fast.h: what limits the number of lanes per CU is table memory, hence
-//   * tables are small and 16-bit, in LDS: literal/length 7-bit first level (128 entries), distance
-//     5-bit (32) = 320 bytes per lane -> 512 lanes (eight waves, two per SIMD) per CU in exactly the
-//     160 KiB of LDS; the second wave of a SIMD issues while the first waits for memory;
-//   * the code lengths of a dynamic block go to the lane's global scratch as they are decoded (sixteen
-//     nibbles per 64-bit store) and come back in symbol order for the two passes of the table builder; the
-//     distance lengths stay in two registers;
-//   * codes longer than the first level (rare in BAM payloads) are decoded canonically, bit by bit,
-//     from per-length counts packed in registers; only their symbols live in global scratch;
-//   * base values and extra-bit counts of length / distance symbols are computed arithmetically;
-//   * input arrives as 8-byte loads issued one step ahead of their use.
+// A wave executes the union of what its 64 lanes do, one instruction at a time, and a lone wave issues an
+// instruction every eight cycles or so: the time of phase 1 is (instructions per trip of the symbol loop, summed
+// over every path ANY lane takes) x (trips of the slowest lane).  The symbol loop is therefore written as one
+// straight line that every lane walks the same way, with selects instead of branches and nothing that loops:
+//   * a trip = up to two literals that the first-level table yields directly, then one full literal/length
+//     symbol and -- computed by all lanes, consumed by those that saw a length -- one distance symbol;
+//   * literal/length codes: a 7-bit first-level table in LDS; longer codes are decoded canonically WITHOUT a
+//     loop -- the 15 bits ahead, bit-reversed, are compared with the first code of every length (one register per
+//     length, eight compare-and-select pairs), which yields length and rank at once; the symbol of that rank sits
+//     in a sorted list beside the table (LDS; ranks beyond 192: global scratch);
+//   * distance codes: no table at all -- the same compare chain over lengths 1..15, the (at most 32) symbols
+//     sorted by code in six registers;
+//   * literals are gathered in a register and stored eight bytes at a time (or when a match follows);
+//   * errors are sticky flags looked at when the lane leaves the loop; every address is clamped.
+// Tables cost 640 bytes of LDS per lane: 256 lanes (one wave per SIMD) per CU.
 //
 // Replaces, on the device, the BGZF inflation that the reference gets from pysam / htslib
 // (te_count/te_count.py:65,190,351); follows RFC 1951 only.
@@ -39,41 +40,41 @@
 #else
 #define TEC_HD inline
 #endif
+// Hides a value from the optimiser (device code): a chain of selects over registers is otherwise turned into a table in
+// scratch memory that is read with a computed index -- a memory access in the middle of the symbol loop.
+#ifdef __HIP_DEVICE_COMPILE__
+#define TEC_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define TEC_OPAQUE(x) (void)(x)
+#endif
 
 namespace tec_ginf {
 
-#ifndef TEC_GINF_LITROOT
-#define TEC_GINF_LITROOT 7
-#endif
-constexpr int kLitRoot = TEC_GINF_LITROOT;
-#ifndef TEC_GINF_DISTROOT
-#define TEC_GINF_DISTROOT 5
-#endif
-constexpr int kDistRoot = TEC_GINF_DISTROOT;
+constexpr int kLitRoot = 7;
 constexpr uint32_t kLitEntries = 1u << kLitRoot;
-constexpr uint32_t kDistEntries = 1u << kDistRoot;
-constexpr uint32_t kEntriesPerLane = kLitEntries + kDistEntries;  // u16 each: 640 bytes
-constexpr uint32_t kLenWords = 20;                                 // code lengths of a dynamic block: 320 nibbles in 64-bit words (global)
-constexpr uint32_t kLongSymsPerLane = 320;                            // symbols of codes longer than the first level (u16, global)
-constexpr uint32_t kInPad = 16;                                       // readable bytes the caller guarantees behind the input
+constexpr uint32_t kLongLds = 192;                                  // long-code symbols kept beside the table
+constexpr uint32_t kEntriesPerLane = kLitEntries + kLongLds;        // u16 each: 640 bytes
+constexpr uint32_t kLenWords = 20;                                  // code lengths of a dynamic block: 320 nibbles in 64-bit words (global)
+constexpr uint32_t kLongSymsPerLane = 320;                          // sorted long-code symbols by rank; ranks >= kLongLds live in global scratch
+constexpr uint32_t kInPad = 16;                                     // readable bytes the caller guarantees behind the input
 
 // Reasons a block is handed back to the host's referee decoder (zlib / inflate_fast.h).
 enum : int { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadCode = 4, kBadSymbol = 5, kBadDistance = 6,
              kOutputOverrun = 7, kInputOverrun = 8, kShortOutput = 9, kTokenOverrun = 10 };
 
 // ---- tokens: what phase 1 hands to phase 2, one 32-bit word per match
-//   bits 31:30  kind   0 nothing (padding), 2 match, 3 skip
-//   match       bits 29:23 bytes already in place in front of the match (literals, stored bytes: 0..127),
-//               bits 22:15 length - 3 (0..255), bits 14:0 distance - 1
-//   skip        bits 19:0 bytes already in place (a run longer than 127, or the tail behind the last match)
-// A block of n bytes has at most n / 3 + n / 128 + 2 tokens.
-constexpr uint32_t kTokMatch = 2u << 30, kTokSkip = 3u << 30;
-constexpr uint32_t kTokMaxBefore = 127u, kTokMaxSkip = 0xFFFFFu;
-TEC_HD uint32_t tok_before(uint32_t t) { return (t >> 30) == 2u ? (t >> 23) & 127u : ((t >> 30) == 3u ? t & kTokMaxSkip : 0u); }
-TEC_HD uint32_t tok_match_len(uint32_t t) { return (t >> 30) == 2u ? ((t >> 15) & 0xFFu) + 3u : 0u; }
+//   match   bit 31 set, bits 30:23 bytes already in place in front of the match (literals, stored bytes: 0..255),
+//           bits 22:15 length - 3 (0..255), bits 14:0 distance - 1
+//   skip    bit 31 clear, bits 30:0 bytes already in place (a run longer than 255, or the tail behind the last match;
+//           0 = nothing)
+// A block of n bytes has at most n / 3 + n / 256 + 2 tokens.
+constexpr uint32_t kTokMatch = 1u << 31;
+constexpr uint32_t kTokMaxBefore = 255u;
+TEC_HD uint32_t tok_before(uint32_t t) { return (t >> 31) ? (t >> 23) & 255u : t; }
+TEC_HD uint32_t tok_match_len(uint32_t t) { return (t >> 31) ? ((t >> 15) & 255u) + 3u : 0u; }
 
-// Host sink: a growing array.  (The device sink, gbam.hip, packs four tokens per 16-byte store into pages
-// drawn from a pool.)  put() returns false when the sink is full: the block is then handed to the referee.
+// Host sink: a growing array.  (The device sink, gbam.hip, writes into pages drawn from a pool.)  put() returns
+// false when the sink is full: the block is then handed to the referee.
 struct VectorSink {
     uint32_t* tok;
     uint32_t cap, n = 0;
@@ -103,26 +104,28 @@ inline bool resolve_tokens(const uint32_t* tok, uint32_t n, uint8_t* out, uint32
     return op == out_len;
 }
 
-// Per-lane memory.  The device instantiation keeps `tab` in LDS and the long-code symbols in global
-// memory; the host instantiation uses plain arrays.
-//   uint32_t tab(uint32_t i) / void set_tab(uint32_t i, uint32_t v)     i < kEntriesPerLane
-//   uint32_t sym(uint32_t i) / void set_sym(uint32_t i, uint32_t v)     i < kLongSymsPerLane
+// Per-lane memory.  The device instantiation keeps `tab` and the head of the long-symbol list in LDS, the rest in
+// global memory; the host instantiation uses plain arrays.
+//   uint32_t tab(uint32_t i) / void set_tab(uint32_t i, uint32_t v)     i < kLitEntries
+//   uint32_t lsym(uint32_t i) / void set_lsym(uint32_t i, uint32_t v)   i < kLongSymsPerLane
+//   uint32_t lsym_near(uint32_t i)                                       i < kLongLds: the part of the list that is always at hand
 //   uint64_t lenw(uint32_t k) / void set_lenw(uint32_t k, uint64_t v)   k < kLenWords
 struct HostMem {
-    uint16_t t[kEntriesPerLane];
+    uint16_t t[kLitEntries];
     uint16_t s[kLongSymsPerLane];
     uint64_t lw[kLenWords];
     uint64_t lenw(uint32_t k) const { return lw[k]; }
     void set_lenw(uint32_t k, uint64_t v) { lw[k] = v; }
     uint32_t tab(uint32_t i) const { return t[i]; }
     void set_tab(uint32_t i, uint32_t v) { t[i] = (uint16_t)v; }
-    uint32_t sym(uint32_t i) const { return s[i]; }
-    void set_sym(uint32_t i, uint32_t v) { s[i] = (uint16_t)v; }
+    uint32_t lsym(uint32_t i) const { return s[i]; }
+    uint32_t lsym_near(uint32_t i) const { return s[i]; }
+    void set_lsym(uint32_t i, uint32_t v) { s[i] = (uint16_t)v; }
 };
 
 // The code lengths of a dynamic block, four bits each, are written once in symbol order (sixteen per
 // 64-bit word, to the lane's global scratch: stores do not stall the lane) and read back in symbol
-// order by the two passes of build_tables (twenty dependent loads per pass).
+// order by the two passes of the table builder (twenty dependent loads per pass).
 template <class Mem>
 struct LenWriter {
     Mem& m;
@@ -186,10 +189,55 @@ struct NextCodes {
     }
 };
 
-// What the canonical (bit by bit) decoder of codes longer than the first level needs.
-struct LongCodes {
-    Counts counts;
-    uint32_t first;  // first code of length root+1, i.e. puff's `first` after the iteration len = root
+// Canonical decoding without a loop.  The codes of a canonical Huffman code, padded with zeros to 15 bits, are
+// ordered by length: length l owns [E[l-1], E[l]) with E[l] = (first code of length l + number of such codes)
+// << (15 - l), E non-decreasing.  For lengths l = kLo .. 14 one register q[l - kLo] = E[l] << 16 | R[l + 1] << 4 |
+// (l + 1), R[l] = rank of the first code of length l among the codes this chain serves (those of kLo bits or more);
+// the last register not above (c << 16 | 0xFFFF) names the length of the 15 bits c, the padded first code of that
+// length and its rank.
+template <int kLo>
+struct Chain {
+    uint32_t q[15 - kLo];
+    uint32_t sel0;  // E[kLo - 1] << 16 | 0 << 4 | kLo
+    uint32_t e15;   // E[15]: 15 bits at or above it are no code
+    // c: the next 15 bits of the stream, first bit in bit 14.  Returns the rank; *len the code length; *bad: no code.
+    TEC_HD uint32_t find(uint32_t c, uint32_t* len, bool* bad) const {
+        const uint32_t cq = (c << 16) | 0xFFFFu;
+        uint32_t sel = sel0;
+#pragma unroll
+        for (int i = 0; i < 15 - kLo; ++i) sel = cq >= q[i] ? q[i] : sel;
+        *len = sel & 15u;
+        *bad = c >= e15;
+        return ((sel >> 4) & 0xFFFu) + ((c - (sel >> 16)) >> (15u - (sel & 15u)));
+    }
+};
+
+// The (at most 32) distance symbols sorted by code: five bits each, six per register.  (Six scalars, not an array:
+// an array picked by a computed index ends up in scratch memory.)
+struct DistSyms {
+    uint32_t w0, w1, w2, w3, w4, w5;
+    TEC_HD void clear() { w0 = w1 = w2 = w3 = w4 = w5 = 0; }
+    TEC_HD void set(uint32_t rank, uint32_t sym) {  // rank < 36, once per rank
+        const uint32_t r = (rank * 43u) >> 8, v = sym << (5u * (rank - 6u * r));
+        w0 |= r == 0 ? v : 0u;
+        w1 |= r == 1 ? v : 0u;
+        w2 |= r == 2 ? v : 0u;
+        w3 |= r == 3 ? v : 0u;
+        w4 |= r == 4 ? v : 0u;
+        w5 |= r == 5 ? v : 0u;
+    }
+    TEC_HD uint32_t get(uint32_t rank) const {  // rank < 36
+        const uint32_t r = (rank * 43u) >> 8;
+        uint32_t v = w0;
+        v = r == 1 ? w1 : v;
+        TEC_OPAQUE(v);
+        v = r == 2 ? w2 : v;
+        v = r == 3 ? w3 : v;
+        TEC_OPAQUE(v);
+        v = r == 4 ? w4 : v;
+        v = r == 5 ? w5 : v;
+        return (v >> (5u * (rank - 6u * r))) & 31u;
+    }
 };
 
 // Input: 64-bit bit buffer fed 32 bits at a time from a two-deep queue of 8-byte loads (the load of
@@ -201,7 +249,6 @@ struct BitReader {
     uint64_t buf, cur, nxt;
     uint32_t cnt;       // valid bits in buf
     uint32_t cur_left;  // bytes of `cur` not yet moved into buf (8, 4 or 0)
-    uint32_t taken;     // bytes of the stream moved into buf so far
     TEC_HD uint64_t load8() {
         uint64_t v;
         memcpy(&v, lp < in_end ? lp : in_end, 8);  // never beyond in_end + 8
@@ -215,23 +262,21 @@ struct BitReader {
         cur = load8();
         nxt = load8();
         cur_left = 8;
-        taken = (uint32_t)(from - in);
     }
-    TEC_HD void refill() {  // at least 32 valid bits afterwards
-        if (cnt <= 32u) {
-            if (cur_left == 0u) {
-                cur = nxt;
-                nxt = load8();
-                cur_left = 8;
-            }
-            buf |= (cur & 0xFFFFFFFFull) << cnt;
-            cur >>= 32;
-            cur_left -= 4u;
-            cnt += 32u;
-            taken += 4u;
+    TEC_HD void refill() {  // at least 33 valid bits afterwards
+        const bool need = cnt <= 32u;
+        if (need && cur_left == 0u) {
+            cur = nxt;
+            nxt = load8();
+            cur_left = 8;
         }
+        buf |= need ? (cur & 0xFFFFFFFFull) << cnt : 0ull;
+        cur = need ? cur >> 32 : cur;
+        cur_left -= need ? 4u : 0u;
+        cnt += need ? 32u : 0u;
     }
     TEC_HD uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+    TEC_HD uint32_t ahead15() const { return __builtin_bitreverse32((uint32_t)buf) >> 17; }  // the next 15 bits, first bit on top
     TEC_HD void drop(uint32_t n) {
         buf >>= n;
         cnt -= n;
@@ -241,84 +286,116 @@ struct BitReader {
         drop(n);
         return v;
     }
+    // bytes of the stream moved into buf so far (two loads are ahead of `cur`'s unused part)
+    TEC_HD uint32_t taken() const { return (uint32_t)(lp - in) - 8u - cur_left; }
     // stream position (bytes) of the first bit that has not been consumed, rounded down
-    TEC_HD uint32_t byte_pos() const { return taken - (cnt >> 3); }
-    TEC_HD bool overrun() const { return (uint64_t)taken * 8u - cnt > (uint64_t)(in_end - in) * 8u; }
-    TEC_HD bool far_overrun() const { return taken > (uint32_t)(in_end - in) + 16u; }
+    TEC_HD uint32_t byte_pos() const { return taken() - (cnt >> 3); }
+    TEC_HD bool overrun() const { return (uint64_t)taken() * 8u - cnt > (uint64_t)(in_end - in) * 8u; }
+    TEC_HD bool far_overrun() const { return taken() > (uint32_t)(in_end - in) + 16u; }
 };
 
 TEC_HD uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32u - len); }
 
-// Canonical Huffman tables of one code (RFC 1951 3.2.2).  lens(i), i < n: code lengths.  Entries
-// [tab_base, tab_base + 2^root): (symbol << 4) | length for codes of at most `root` bits, 0 for
-// prefixes of longer codes and for unused patterns.  Symbols of longer codes go, sorted by (length,
-// value), to the lane's global list from sym_base on.  Returns false for an over-subscribed code or
-// an incomplete one that zlib would refuse (inftrees.c: incomplete is allowed only for no code at
-// all, or for a literal/length or distance code that consists of a single one-bit code).
-template <class Mem, class LenFn>
-TEC_HD bool build_tables(Mem& m, LenFn lens, uint32_t n, uint32_t root, uint32_t tab_base, uint32_t sym_base, bool is_cl,
-                         LongCodes* lc) {
-    Counts cnt;
-    cnt.clear();
+// Counts the code lengths lens(i), i < n, and checks the code as zlib does (inftrees.c): over-subscribed codes are
+// refused, incomplete ones too unless there is no code at all, or the code is a literal/length or distance code of
+// a single one-bit code.
+template <class LenFn>
+TEC_HD bool count_lengths(LenFn lens, uint32_t n, bool is_cl, Counts* cnt) {
+    cnt->clear();
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t l = lens(i);
-        if (l) cnt.add(l);
+        if (l) cnt->add(l);
     }
     int32_t left = 1;
-    uint32_t max_len = 0, code = 0, n_long = 0;
-    NextCodes next;
-    next.clear();
-    Counts long_offs;  // where the symbols of each length > root start in the lane's long-symbol list
-    long_offs.clear();
-    lc->counts = cnt;
-    lc->first = 0;
+    uint32_t max_len = 0;
+#pragma unroll
     for (uint32_t l = 1; l <= 15u; ++l) {
-        const uint32_t c = cnt.get(l);
+        const uint32_t c = cnt->get(l);
         left = (left << 1) - (int32_t)c;
         if (left < 0) return false;
-        if (c) max_len = l;
+        max_len = c ? l : max_len;
+    }
+    return !(left > 0 && max_len > 0 && (is_cl || max_len != 1u));
+}
+
+// The chain registers of a counted code: codes of kLo bits or more.
+template <int kLo>
+TEC_HD void make_chain(const Counts& cnt, Chain<kLo>* ch) {
+    uint32_t code = 0, rank = 0;
+    ch->sel0 = (uint32_t)kLo;  // (E[0] = 0; overwritten below when kLo > 1)
+#pragma unroll
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        const uint32_t c = cnt.get(l);
+        code += c;                                  // one past the last code of length l
+        const uint32_t e = code << (15u - l);       // <= 32768 for a code that is not over-subscribed
+        if (l >= (uint32_t)kLo) rank += c;          // rank of the first code of length l + 1
+        if (l + 1u == (uint32_t)kLo) ch->sel0 = (e << 16) | (uint32_t)kLo;
+        if (l >= (uint32_t)kLo && l <= 14u) ch->q[l - kLo] = (e << 16) | (rank << 4) | (l + 1u);
+        if (l == 15u) ch->e15 = e;
+        code <<= 1;
+    }
+}
+
+// Literal/length code (and the code-length code): first-level entries [0, 2^kLitRoot): (symbol << 4) | length for
+// codes of at most kLitRoot bits, 0 for prefixes of longer codes and for unused patterns; the symbols of longer
+// codes, sorted by (length, value), to m.lsym; the chain for them.  False: see count_lengths.
+template <class Mem, class LenFn>
+TEC_HD bool build_lit(Mem& m, LenFn lens, uint32_t n, bool is_cl, Chain<kLitRoot + 1>* ch) {
+    Counts cnt;
+    if (!count_lengths(lens, n, is_cl, &cnt)) return false;
+    make_chain(cnt, ch);
+    NextCodes next;
+    next.clear();
+    Counts long_offs;  // where the symbols of each length > root start in the long-symbol list
+    long_offs.clear();
+    uint32_t code = 0, n_long = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        const uint32_t c = cnt.get(l);
         next.set(l, code);
         code = (code + c) << 1;
-        if (l == root) lc->first = code;  // first code of length root + 1
-        if (l > root) {
+        if (l > (uint32_t)kLitRoot) {
             long_offs.add_n(l, n_long);
             n_long += c;
         }
     }
-    if (left > 0 && max_len > 0 && (is_cl || max_len != 1u)) return false;
-    for (uint32_t i = 0; i < (1u << root); ++i) m.set_tab(tab_base + i, 0u);
+    for (uint32_t i = 0; i < kLitEntries; ++i) m.set_tab(i, 0u);
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t l = lens(s);
         if (!l) continue;
-        if (l <= root) {
+        if (l <= (uint32_t)kLitRoot) {
             const uint32_t e = (s << 4) | l;
-            for (uint32_t x = bitrev(next.take(l), l); x < (1u << root); x += 1u << l) m.set_tab(tab_base + x, e);
-        } else {  // first-level entries of its prefix stay 0: the long-code path
-            m.set_sym(sym_base + long_offs.get(l), s);
+            for (uint32_t x = bitrev(next.take(l), l); x < kLitEntries; x += 1u << l) m.set_tab(x, e);
+        } else {  // first-level entries of its prefix stay 0: the chain decodes it
+            m.set_lsym(long_offs.get(l), s);
             long_offs.add(l);
         }
     }
     return true;
 }
 
-// One symbol of a code whose first-level lookup missed: canonical decoding from bit root+1 on.
-// Returns the symbol, or 0xFFFF if the bits are no code.
-template <class Mem>
-TEC_HD uint32_t decode_long(const Mem& m, BitReader& br, uint32_t root, uint32_t sym_base, const LongCodes& lc) {
-    uint32_t code = bitrev(br.peek(root), root) << 1;
-    br.drop(root);
-    uint32_t first = lc.first, index = 0;
-#pragma unroll 1
-    for (uint32_t l = root + 1u; l <= 15u; ++l) {
-        code |= br.peek(1);
-        br.drop(1);
-        const uint32_t c = lc.counts.get(l);
-        if (code - first < c) return m.sym(sym_base + index + (code - first));
-        index += c;
-        first = (first + c) << 1;
-        code <<= 1;
+// Distance code: chain over all lengths, the symbols sorted by (length, value) in registers.
+template <class LenFn>
+TEC_HD bool build_dist(LenFn lens, uint32_t n, Chain<1>* ch, DistSyms* ds) {
+    Counts cnt;
+    if (!count_lengths(lens, n, false, &cnt)) return false;
+    make_chain(cnt, ch);
+    Counts offs;
+    offs.clear();
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        offs.add_n(l, rank);
+        rank += cnt.get(l);
     }
-    return 0xFFFFu;
+    ds->clear();
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t l = lens(s);
+        if (!l) continue;
+        ds->set(offs.get(l), s);
+        offs.add(l);
+    }
+    return true;
 }
 
 // Phase 1: walks the raw DEFLATE stream in[0, in_len), which inflates to exactly out_len bytes: literal and stored
@@ -330,8 +407,25 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
     br.in = in;
     br.in_end = in + in_len;
     br.start(in);
-    uint32_t op = 0;
-    uint32_t run = 0;  // bytes in place since the last token
+    uint32_t opb = 0;   // bytes of `out` stored (or left to phase 2) so far
+    uint64_t acc = 0;   // literals decoded but not stored yet: out[opb, opb + nacc)
+    uint32_t nacc = 0;
+    uint32_t run = 0;   // bytes in place since the last token (nacc included)
+    // stores the gathered literals: eight bytes at once (what lies above nacc is zero and belongs to bytes that this
+    // lane or phase 2 writes later) unless that would touch the next block's bytes
+    auto flush = [&]() {
+        if (nacc == 0u) return;
+        if (opb + 8u <= out_len) {
+            memcpy(out + opb, &acc, 8);
+        } else {
+            uint64_t a = acc;
+#pragma unroll 1
+            for (uint32_t j = 0; j < nacc; ++j, a >>= 8) out[opb + j] = (uint8_t)a;  // (opb + nacc <= out_len)
+        }
+        opb += nacc;
+        acc = 0;
+        nacc = 0;
+    };
     bool last = false;
     while (!last) {
         br.refill();
@@ -347,9 +441,10 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if ((len ^ nlen) != 0xFFFFu) return kBadStored;
             const uint32_t pos = br.byte_pos();  // whole bytes still in the bit buffer belong to the payload
             if (pos > in_len || in_len - pos < len) return kInputOverrun;
-            if (out_len - op < len) return kOutputOverrun;
+            flush();
+            if (out_len - opb < len) return kOutputOverrun;
             const uint8_t* src = in + pos;
-            uint8_t* q = out + op;
+            uint8_t* q = out + opb;
             uint32_t k = 0;
             for (; k + 8u <= len; k += 8u) {
                 uint64_t v;
@@ -357,7 +452,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 memcpy(q + k, &v, 8);
             }
             for (; k < len; ++k) q[k] = src[k];
-            op += len;
+            opb += len;
             run += len;
             br.start(src + len);
             continue;
@@ -365,6 +460,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
         uint32_t hlit = 288, hdist = 32;
         bool fixed = false;
         uint64_t dl_lo = 0x5555555555555555ull, dl_hi = 0x5555555555555555ull;  // distance code lengths, 4 bits each (fixed: all 5)
+        Chain<kLitRoot + 1> ll;
         if (type == 1u) {  // fixed codes (RFC 1951 3.2.6)
             fixed = true;
         } else {  // dynamic codes: the code-length code first (3.2.7)
@@ -384,10 +480,8 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
                 const uint32_t s = i < 12u ? (uint32_t)(ord_lo >> (5u * i)) & 31u : (uint32_t)(ord_hi >> (5u * (i - 12u))) & 31u;
                 cl |= (uint64_t)br.get(3) << (3u * s);
             }
-            LongCodes unused;
-            // its 7-bit table sits in the (not yet built) literal/length area; no code is longer than 7 bits
-            if (!build_tables(m, [&](uint32_t i) { return (uint32_t)(cl >> (3u * i)) & 7u; }, 19u, 7u, 0u, 0u, true, &unused))
-                return kBadCodeLengths;
+            // its table sits in the (not yet built) literal/length table; no code is longer than 7 bits
+            if (!build_lit(m, [&](uint32_t i) { return (uint32_t)(cl >> (3u * i)) & 7u; }, 19u, true, &ll)) return kBadCodeLengths;
             dl_lo = dl_hi = 0;
             LenWriter<Mem> lw{m};
             uint32_t prev = 0;
@@ -433,83 +527,91 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (br.overrun()) return kInputOverrun;
             if (!has_eob) return kBadCodeLengths;  // no end-of-block code
         }
-        LongCodes ll, ld;
-        uint64_t lcur = 0;  // both passes of build_tables ask for the lengths in symbol order
+        Chain<1> ld;
+        DistSyms dsyms;
+        uint64_t lcur = 0;  // both passes of the builder ask for the lengths in symbol order
         auto lit_len = [&](uint32_t i) -> uint32_t {
             if (fixed) return i < 144u ? 8u : (i < 256u ? 9u : (i < 280u ? 7u : 8u));
             if ((i & 15u) == 0u) lcur = m.lenw(i >> 4);
             return (uint32_t)(lcur >> (4u * (i & 15u))) & 15u;
         };
-        if (!build_tables(m, lit_len, hlit, (uint32_t)kLitRoot, 0u, 0u, false, &ll)) return kBadCode;
-        if (!build_tables(m, [&](uint32_t i) { return (uint32_t)((i < 16u ? dl_lo : dl_hi) >> (4u * (i & 15u))) & 15u; }, hdist,
-                          (uint32_t)kDistRoot, kLitEntries, 288u, false, &ld))
+        if (!build_lit(m, lit_len, hlit, false, &ll)) return kBadCode;
+        if (!build_dist([&](uint32_t i) { return (uint32_t)((i < 16u ? dl_lo : dl_hi) >> (4u * (i & 15u))) & 15u; }, hdist, &ld, &dsyms))
             return kBadCode;
-        // ---- the block's symbols
-        for (;;) {
-            br.refill();
-            uint32_t e = m.tab(br.peek(kLitRoot));
-            uint32_t s;
-            if (e & 15u) {
-                br.drop(e & 15u);
-                s = e >> 4;
-            } else {
-                s = decode_long(m, br, (uint32_t)kLitRoot, 0u, ll);
-                if (s == 0xFFFFu) return kBadSymbol;
-            }
-            if (s < 256u) {
-                if (op >= out_len) return kOutputOverrun;
-                out[op++] = (uint8_t)s;
-                ++run;
-                // up to two more literals from the bits already in the buffer (>= 18 after any first code, and a
-                // first-level code has at most kLitRoot bits): lanes in a literal run advance three symbols in the
-                // time a neighbour lane spends on one match
+        // ---- the block's symbols: one straight line per trip (see the head of this file)
+        int err = kOk;
+        bool eob = false;
+        while (!eob && err == kOk) {
+            br.refill();  // >= 33 bits
+            // up to two literals straight from the first-level table (the second only if 20 bits stay for the full symbol)
 #pragma unroll
-                for (int extra = 0; extra < 2; ++extra) {
-                    const uint32_t e2 = m.tab(br.peek(kLitRoot));
-                    if ((e2 & 15u) == 0u || (e2 >> 4) >= 256u || op >= out_len) break;
-                    br.drop(e2 & 15u);
-                    out[op++] = (uint8_t)(e2 >> 4);
-                    ++run;
-                }
-                continue;
+            for (int stage = 0; stage < 2; ++stage) {
+                const uint32_t e = m.tab(br.peek(kLitRoot));
+                const uint32_t l = e & 15u;
+                const bool ok = l != 0u && (e >> 4) < 256u && opb + nacc < out_len && (stage == 0 || br.cnt >= 20u + l);
+                br.drop(ok ? l : 0u);
+                acc |= (uint64_t)(ok ? e >> 4 : 0u) << (8u * nacc);
+                nacc += ok ? 1u : 0u;
+                run += ok ? 1u : 0u;
             }
-            if (s == 256u) break;
-            s -= 257u;
-            if (s >= 29u) return kBadSymbol;
+            // one literal/length symbol, whatever its code
+            const uint32_t e = m.tab(br.peek(kLitRoot));
+            uint32_t llen;
+            bool lbad;
+            uint32_t rank = ll.find(br.ahead15(), &llen, &lbad);
+            rank = rank < kLongSymsPerLane ? rank : kLongSymsPerLane - 1u;
+            uint32_t slong = m.lsym_near(rank < kLongLds ? rank : 0u);
+            const bool direct = (e & 15u) != 0u;
+            if (!direct && rank >= kLongLds) slong = m.lsym(rank);  // (rare: more than kLongLds symbols with long codes)
+            uint32_t s = direct ? e >> 4 : slong;
+            br.drop(direct ? e & 15u : llen);
+            err = !direct && lbad ? (int)kBadSymbol : err;
+            const bool is_lit = s < 256u, room = opb + nacc < out_len;
+            err = is_lit && !room ? (int)kOutputOverrun : err;
+            acc |= (uint64_t)(is_lit && room ? s : 0u) << (8u * (nacc & 7u));
+            nacc += is_lit && room ? 1u : 0u;
+            run += is_lit && room ? 1u : 0u;
+            eob = s == 256u;
+            const bool is_len = s > 256u;
+            s = is_len ? s - 257u : 0u;
+            err = s >= 29u ? (int)kBadSymbol : err;
             // length: symbols 0..7 -> 3..10, then groups of four per extra bit, 28 -> 258
-            const uint32_t lx = s < 8u ? 0u : (s == 28u ? 0u : (s - 4u) >> 2);
-            uint32_t length = s < 8u ? 3u + s : (s == 28u ? 258u : 3u + ((4u + (s & 3u)) << lx));
-            length += br.get(lx);  // (the refill at the top left >= 33 bits: a 15-bit code and 5 extra bits fit)
-            br.refill();           // >= 33 bits again: a 15-bit distance code and 13 extra bits fit
-            uint32_t d;
-            e = m.tab(kLitEntries + br.peek(kDistRoot));
-            if (e & 15u) {
-                br.drop(e & 15u);
-                d = e >> 4;
-            } else {
-                d = decode_long(m, br, (uint32_t)kDistRoot, 288u, ld);
-                if (d == 0xFFFFu) return kBadDistance;
+            const uint32_t lx = s < 8u ? 0u : (s >= 28u ? 0u : (s - 4u) >> 2);
+            uint32_t length = s < 8u ? 3u + s : (s >= 28u ? 258u : 3u + ((4u + (s & 3u)) << lx));
+            length += br.get(lx);  // (>= 33 bits at the top, at most 14 + 15 + 5 used: the second literal left 20 for this symbol)
+            if (is_len || eob || nacc > 5u) flush();  // (the next trip may add three literals)
+            br.refill();  // >= 33 bits again: a 15-bit distance code and 13 extra bits fit
+            uint32_t dlen;
+            bool dbad;
+            uint32_t drank = ld.find(br.ahead15(), &dlen, &dbad);
+            const uint32_t d = dsyms.get(drank < 35u ? drank : 35u);
+            if (is_len) {
+                br.drop(dlen);
+                err = dbad || d >= 30u ? (int)kBadDistance : err;
+                const uint32_t dc = d < 30u ? d : 0u;
+                const uint32_t dx = dc < 4u ? 0u : (dc - 2u) >> 1;
+                uint32_t dist = dc < 4u ? 1u + dc : 1u + ((2u + (dc & 1u)) << dx);
+                dist += br.get(dx);
+                err = dist > opb ? (int)kBadDistance : err;
+                err = out_len - opb < length ? (int)kOutputOverrun : err;
+                if (err == kOk) {
+                    if (run > kTokMaxBefore) {  // a long run of bytes in place gets a token of its own
+                        if (!sink.put(run)) err = kTokenOverrun;
+                        run = 0;
+                    }
+                    if (!sink.put(kTokMatch | (run << 23) | ((length - 3u) << 15) | (dist - 1u))) err = kTokenOverrun;
+                    run = 0;
+                    opb += length;
+                }
             }
-            if (d >= 30u) return kBadDistance;
-            const uint32_t dx = d < 4u ? 0u : (d - 2u) >> 1;
-            uint32_t dist = d < 4u ? 1u + d : 1u + ((2u + (d & 1u)) << dx);
-            dist += br.get(dx);
-            if (dist > op) return kBadDistance;
-            if (out_len - op < length) return kOutputOverrun;
-            if (br.far_overrun()) return kInputOverrun;
-            op += length;
-            if (run > kTokMaxBefore) {  // a long run of bytes in place gets a token of its own
-                if (!sink.put(kTokSkip | run)) return kTokenOverrun;
-                run = 0;
-            }
-            if (!sink.put(kTokMatch | (run << 23) | ((length - 3u) << 15) | (dist - 1u))) return kTokenOverrun;
-            run = 0;
+            err = br.far_overrun() ? (int)kInputOverrun : err;
         }
-        if (br.far_overrun()) return kInputOverrun;
+        if (err != kOk) return err;
     }
+    flush();
     if (br.overrun()) return kInputOverrun;
-    if (run && !sink.put(kTokSkip | run)) return kTokenOverrun;  // (run <= out_len <= 65 536)
-    return op == out_len ? kOk : kShortOutput;
+    if (run && !sink.put(run)) return kTokenOverrun;  // (run <= out_len <= 65 536)
+    return opb == out_len ? kOk : kShortOutput;
 }
 
 }  // namespace tec_ginf
