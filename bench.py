@@ -29,8 +29,8 @@ import time
 
 import numpy as np
 
-if int(os.environ.get('GPU_MAX_HW_QUEUES') or 0) < 8:
-    os.environ['GPU_MAX_HW_QUEUES'] = '8'  # before anything initialises HIP (see te_counter_amd/__init__.py)
+if int(os.environ.get('GPU_MAX_HW_QUEUES') or 0) < 16:
+    os.environ['GPU_MAX_HW_QUEUES'] = '16'  # before anything initialises HIP (see te_counter_amd/__init__.py)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

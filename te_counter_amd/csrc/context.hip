@@ -27,9 +27,9 @@ extern "C" int tec_create(int device_id, tec_ctx** out) {
     *out = nullptr;
     // the BAM decoder keeps the inflate launches of several chunks in flight, each on a stream of its own: with four
     // hardware queues per process (HIP's default) this library's streams share queues and those launches run one after
-    // the other.  Raised to eight unless the caller asked for more (effective only if HIP is not initialised yet)
+    // the other.  Raised to sixteen (a process that holds several contexts and a tensor library has a dozen streams) unless the caller asked for more (effective only if HIP is not initialised yet)
     const char* hwq = getenv("GPU_MAX_HW_QUEUES");
-    if (!hwq || atoi(hwq) < 8) setenv("GPU_MAX_HW_QUEUES", "8", 1);
+    if (!hwq || atoi(hwq) < 16) setenv("GPU_MAX_HW_QUEUES", "16", 1);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)

@@ -436,7 +436,7 @@ struct GbamBuffers {
     // Chunk k's two inflate kernels go to stream k % kStreams, phase 2 in order behind phase 1: the launches of up to
     // kStreams chunks overlap when the streams sit on different hardware queues.  A process has GPU_MAX_HW_QUEUES of them
     // (HIP's default: four) for all its streams and which one a stream gets is not ours to choose: with four, two of these
-    // streams share a queue and their 30 ms launches run back to back; tec_create asks for eight before HIP initialises.
+    // streams share a queue and their launches run back to back; tec_create asks for sixteen before HIP initialises.
     hipStream_t s_infl[kStreams] = {};
     int cur_buf = 0;                      // buffer of the chunk being consumed (the carry sits in front of its stream)
     Piece pieces[3];  // one being walked / copied, one being read, one whose copy to HBM drains
