@@ -44,8 +44,10 @@
 // scratch memory that is read with a computed index -- a memory access in the middle of the symbol loop.
 #ifdef __HIP_DEVICE_COMPILE__
 #define TEC_OPAQUE(x) asm volatile("" : "+v"(x))
+#define TEC_OPAQUE_ORDERED(x) asm volatile("" : "+v"(x) : : "memory")  // ... and memory accesses stay on their side of it
 #else
 #define TEC_OPAQUE(x) (void)(x)
+#define TEC_OPAQUE_ORDERED(x) (void)(x)
 #endif
 
 namespace tec_ginf {
@@ -240,19 +242,27 @@ struct DistSyms {
     }
 };
 
-// Input: 64-bit bit buffer fed 32 bits at a time from a two-deep queue of 8-byte loads (the load of
-// the word after next is in flight while the current one is consumed).
+// Input: 64-bit bit buffer fed 32 bits at a time from a queue of 8-byte words: `cur` (being moved into the buffer),
+// `nxt`, and the word behind it, which EVERY refill loads again -- whether or not the queue moves -- while the queue
+// takes the value that an EARLIER refill loaded: a load is never waited for in the refill that issued it.  (A load placed
+// under "if the queue moves" is waited for on the spot -- its value has to be merged with the old one where the branch
+// ends -- and a lone wave then stands still for a memory latency in every trip of the symbol loop.)
+//   refill()      takes the value of the refill before it (always the word at the current address: it was loaded after
+//                 that refill had moved the queue, if it did);
+//   refill_hot()  for the symbol loop, whose two refills per trip alternate between two slots, each taking the value
+//                 loaded two refills earlier -- the queue moves at most every second refill (a word feeds two), so that
+//                 value was loaded from the address that is still current.  hot_enter() / hot_exit() around the loop.
 struct BitReader {
     const uint8_t* in;
     const uint8_t* in_end;
-    const uint8_t* lp;  // address of the next 8-byte load
+    const uint8_t* lp;  // address of the word behind `nxt`
     uint64_t buf, cur, nxt;
+    uint64_t x0, x1;    // the word at lp, as loaded by earlier refills
     uint32_t cnt;       // valid bits in buf
     uint32_t cur_left;  // bytes of `cur` not yet moved into buf (8, 4 or 0)
-    TEC_HD uint64_t load8() {
+    TEC_HD uint64_t load8() const {
         uint64_t v;
         memcpy(&v, lp < in_end ? lp : in_end, 8);  // never beyond in_end + 8
-        lp += 8;
         return v;
     }
     TEC_HD void start(const uint8_t* from) {
@@ -260,21 +270,31 @@ struct BitReader {
         buf = 0;
         cnt = 0;
         cur = load8();
+        lp += 8;
         nxt = load8();
+        lp += 8;
+        x0 = x1 = load8();
         cur_left = 8;
     }
-    TEC_HD void refill() {  // at least 33 valid bits afterwards
+    TEC_HD void refill_hot(uint64_t& slot) {  // at least 33 valid bits afterwards
         const bool need = cnt <= 32u;
-        if (need && cur_left == 0u) {
-            cur = nxt;
-            nxt = load8();
-            cur_left = 8;
-        }
+        const bool adv = need && cur_left == 0u;
+        cur = adv ? nxt : cur;
+        nxt = adv ? slot : nxt;
+        // (the old value of the slot is dead before the load that refills it is issued: loaded value and slot can then
+        // share a register, and nothing has to wait for the load where the loop closes)
+        TEC_OPAQUE_ORDERED(nxt);
+        lp += adv ? 8 : 0;
+        cur_left = adv ? 8u : cur_left;
+        slot = load8();
         buf |= need ? (cur & 0xFFFFFFFFull) << cnt : 0ull;
         cur = need ? cur >> 32 : cur;
         cur_left -= need ? 4u : 0u;
         cnt += need ? 32u : 0u;
     }
+    TEC_HD void refill() { refill_hot(x0); }
+    TEC_HD void hot_enter() { x1 = x0; }  // (the queue has not moved since x0 was loaded)
+    TEC_HD void hot_exit() { x0 = x1; }   // (x1 is the younger load)
     TEC_HD uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
     TEC_HD uint32_t ahead15() const { return __builtin_bitreverse32((uint32_t)buf) >> 17; }  // the next 15 bits, first bit on top
     TEC_HD void drop(uint32_t n) {
@@ -286,7 +306,7 @@ struct BitReader {
         drop(n);
         return v;
     }
-    // bytes of the stream moved into buf so far (two loads are ahead of `cur`'s unused part)
+    // bytes of the stream moved into buf so far (`nxt` and the unused part of `cur` are not)
     TEC_HD uint32_t taken() const { return (uint32_t)(lp - in) - 8u - cur_left; }
     // stream position (bytes) of the first bit that has not been consumed, rounded down
     TEC_HD uint32_t byte_pos() const { return taken() - (cnt >> 3); }
@@ -541,8 +561,9 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
         // ---- the block's symbols: one straight line per trip (see the head of this file)
         int err = kOk;
         bool eob = false;
+        br.hot_enter();
         while (!eob && err == kOk) {
-            br.refill();  // >= 33 bits
+            br.refill_hot(br.x0);  // >= 33 bits
             // up to two literals straight from the first-level table (the second only if 20 bits stay for the full symbol)
 #pragma unroll
             for (int stage = 0; stage < 2; ++stage) {
@@ -561,8 +582,12 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             uint32_t rank = ll.find(br.ahead15(), &llen, &lbad);
             rank = rank < kLongSymsPerLane ? rank : kLongSymsPerLane - 1u;
             uint32_t slong = m.lsym_near(rank < kLongLds ? rank : 0u);
+            TEC_OPAQUE(slong);  // (keeps this read apart from the rare one below: merged, they become one access to "any" memory)
             const bool direct = (e & 15u) != 0u;
-            if (!direct && rank >= kLongLds) slong = m.lsym(rank);  // (rare: more than kLongLds symbols with long codes)
+            if (!direct && rank >= kLongLds) {  // (rare: more than kLongLds symbols with long codes)
+                slong = m.lsym(rank);
+                TEC_OPAQUE(slong);  // (the wait for this load stays inside the branch)
+            }
             uint32_t s = direct ? e >> 4 : slong;
             br.drop(direct ? e & 15u : llen);
             err = !direct && lbad ? (int)kBadSymbol : err;
@@ -580,7 +605,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             uint32_t length = s < 8u ? 3u + s : (s >= 28u ? 258u : 3u + ((4u + (s & 3u)) << lx));
             length += br.get(lx);  // (>= 33 bits at the top, at most 14 + 15 + 5 used: the second literal left 20 for this symbol)
             if (is_len || eob || nacc > 5u) flush();  // (the next trip may add three literals)
-            br.refill();  // >= 33 bits again: a 15-bit distance code and 13 extra bits fit
+            br.refill_hot(br.x1);  // >= 33 bits again: a 15-bit distance code and 13 extra bits fit
             uint32_t dlen;
             bool dbad;
             uint32_t drank = ld.find(br.ahead15(), &dlen, &dbad);
@@ -606,6 +631,7 @@ TEC_HD int inflate_stream(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             }
             err = br.far_overrun() ? (int)kInputOverrun : err;
         }
+        br.hot_exit();
         if (err != kOk) return err;
     }
     flush();

@@ -67,21 +67,18 @@ enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_LONG
 
 }  // namespace
 
-struct tec_sc_state {
-    int stranded = 0, mapq_min = 20;
-    uint64_t bundle_keys = 10000000;
-    uint64_t expected_records = 0;  // of the whole input, if the caller can tell (the BAM decoder can): sizes the survivor arrays
-    uint32_t n_wl = 0, n_class = 0;
+// Device buffers of a single-cell run.  They outlive the run: tec_sc_end parks them on the context (allocating and
+// freeing two dozen arrays of HBM costs more than the kernels of a small run), the next tec_sc_begin on that context
+// takes them over, tec_destroy frees them.  Nothing in them is read before it is written.
+struct ScBuffers {
     dvec<uint64_t> wl;          // 3 words per barcode, big-endian packed, ascending
     dvec<uint32_t> wl_table;    // open-addressing hash over wl: rank + 1, 0 = empty
-    uint32_t wl_mask = 0;
     dvec<int32_t> cls_chrom;    // read-side chromosome class -> index chrom id (-1: not in index)
     dvec<uint8_t> cls_skip;     // '_' or 'alt' in the read-side chromosome string
     // survivors, in file order
     dvec<uint32_t> bcid;
     dvec<uint64_t> u0, u1, u2, rec;
     dvec<int32_t> klass, left, rite;
-    uint64_t n_live = 0, n_seen = 0;
     dvec<unsigned long long> stat;
     // batch temporaries
     dvec<uint32_t> b_live, b_scan, b_bcid;
@@ -93,6 +90,33 @@ struct tec_sc_state {
     dvec<uint32_t> k32a, k32b;
     dvec<int32_t> s_klass, s_left, s_rite;
     dvec<uint8_t> ghead, ihead, counted;
+    // GPU stream time of the phases (events around each entry point's work; includes the short host gaps
+    // between its kernels, so it is an upper bound of the summed kernel time)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void free_all() {
+        wl.release(); wl_table.release(); cls_chrom.release(); cls_skip.release();
+        bcid.release(); u0.release(); u1.release(); u2.release(); rec.release();
+        klass.release(); left.release(); rite.release(); stat.release();
+        b_live.release(); b_scan.release(); b_bcid.release(); b_in.release(); tmp.release();
+        perm.release(); perm2.release(); s_bcid.release(); gid.release(); s_epoch.release();
+        headidx.release(); cnt.release(); first_seen.release(); k64a.release(); k64b.release();
+        s_u0.release(); s_u1.release(); s_u2.release(); k32a.release(); k32b.release();
+        s_klass.release(); s_left.release(); s_rite.release(); ghead.release(); ihead.release();
+        s_rec.release(); marks.release();
+        counted.release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        ev0 = ev1 = nullptr;
+    }
+};
+
+struct tec_sc_state : ScBuffers {
+    int stranded = 0, mapq_min = 20;
+    uint64_t bundle_keys = 10000000;
+    uint64_t expected_records = 0;  // of the whole input, if the caller can tell (the BAM decoder can): sizes the survivor arrays
+    uint32_t n_wl = 0, n_class = 0;
+    uint32_t wl_mask = 0;
+    uint64_t n_live = 0, n_seen = 0;
     uint32_t n_groups = 0, n_epochs = 1;
     bool part1_done = false, sorted = false;
     uint64_t rec_base = 0, max_rec = 0, n_marks = 0;  // global ordinal of this context's first record; largest ordinal anywhere
@@ -104,9 +128,6 @@ struct tec_sc_state {
     std::vector<uint64_t> out_hits, coo_count;
     uint64_t kept_lines = 0, n_queries = 0, n_assigned = 0;
     unsigned long long h_stat[ST_N] = {0};
-    // GPU stream time of the phases (events around each entry point's work; includes the short host gaps
-    // between its kernels, so it is an upper bound of the summed kernel time)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double gpu_ms = 0.0;
 };
 
@@ -652,28 +673,30 @@ inline unsigned bits_for(uint64_t max_value) {
     return b;
 }
 
-void sc_free(tec_sc_state* s) {
+}  // namespace
+
+// Ends the run on this context, if any: its buffers are parked for the next one.
+static void sc_park(tec_ctx* ctx) {
+    tec_sc_state* s = ctx->sc;
     if (!s) return;
-    s->wl.release(); s->wl_table.release(); s->cls_chrom.release(); s->cls_skip.release();
-    s->bcid.release(); s->u0.release(); s->u1.release(); s->u2.release(); s->rec.release();
-    s->klass.release(); s->left.release(); s->rite.release(); s->stat.release();
-    s->b_live.release(); s->b_scan.release(); s->b_bcid.release(); s->b_in.release(); s->tmp.release();
-    s->perm.release(); s->perm2.release(); s->s_bcid.release(); s->gid.release(); s->s_epoch.release();
-    s->headidx.release(); s->cnt.release(); s->first_seen.release(); s->k64a.release(); s->k64b.release();
-    s->s_u0.release(); s->s_u1.release(); s->s_u2.release(); s->k32a.release(); s->k32b.release();
-    s->s_klass.release(); s->s_left.release(); s->s_rite.release(); s->ghead.release(); s->ihead.release();
-    s->s_rec.release(); s->marks.release();
-    s->counted.release();
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    ctx->sc = nullptr;
+    if (ctx->sc_parked) {
+        s->free_all();
+    } else {
+        ctx->sc_parked = new ScBuffers(static_cast<ScBuffers&>(*s));
+    }
     delete s;
 }
 
-}  // namespace
-
+// tec_destroy: the run and the parked buffers go.
 void tec_sc_release(tec_ctx* ctx) {
-    sc_free(ctx->sc);
-    ctx->sc = nullptr;
+    sc_park(ctx);
+    if (ctx->sc_parked) {
+        ScBuffers* b = static_cast<ScBuffers*>(ctx->sc_parked);
+        b->free_all();
+        delete b;
+        ctx->sc_parked = nullptr;
+    }
 }
 
 extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n_whitelist, const uint8_t* whitelist24,
@@ -685,8 +708,14 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
     if (n_class && (!class_index_chrom || !class_skip)) return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: NULL class table");
     if (bundle_keys == 0) return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: bundle_keys must be positive");
     SC_HIP(hipSetDevice(ctx->device));
-    tec_sc_release(ctx);
+    sc_park(ctx);
     tec_sc_state* s = new tec_sc_state();
+    if (ctx->sc_parked) {  // buffers parked by the previous run on this context
+        ScBuffers* b = static_cast<ScBuffers*>(ctx->sc_parked);
+        static_cast<ScBuffers&>(*s) = *b;
+        delete b;
+        ctx->sc_parked = nullptr;
+    }
     ctx->sc = s;
     s->stranded = stranded ? 1 : 0;
     s->mapq_min = mapq_min;
@@ -1552,6 +1581,6 @@ extern "C" int tec_sc_stats(tec_ctx* ctx, tec_sc_stats_t* out) {
 
 extern "C" int tec_sc_end(tec_ctx* ctx) {
     if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_sc_end: NULL context");
-    tec_sc_release(ctx);
+    sc_park(ctx);
     return TEC_OK;
 }

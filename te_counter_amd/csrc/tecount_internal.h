@@ -66,6 +66,7 @@ struct tec_ctx {
 
     // single cell
     tec_sc_state* sc = nullptr;
+    void* sc_parked = nullptr;   // device buffers parked by the last single-cell run (sc.hip)
     void* gbam_cache = nullptr;  // device / pinned buffers parked by the last on-GPU BAM reader (gbam.hip)
 
     // bulk state

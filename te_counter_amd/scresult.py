@@ -15,11 +15,22 @@ class ScResult(Mapping):
         self.coo_cell = np.ascontiguousarray(coo_cell, np.uint32)    # sorted by (cell, name)
         self.coo_name = np.ascontiguousarray(coo_name, np.uint32)
         self.coo_count = np.ascontiguousarray(coo_count, np.uint64)
-        self._index = {n: i for i, n in enumerate(self.names)}
-        order = np.argsort(self.coo_name, kind='stable')             # by name, cells ascending inside
-        self._by_name = order
-        self._starts = np.searchsorted(self.coo_name[order], np.arange(len(self.names) + 1))
+        self._index = None      # name -> row, and the triplets grouped by name: built when the mapping is first
+        self._by_name = None    # looked into (sc_save_result's native writer takes the triplets as they are)
+        self._starts = None
         self._cache = {}
+
+    def _group(self):
+        if self._index is None:
+            self._index = {n: i for i, n in enumerate(self.names)}
+        if self._by_name is None:
+            n = len(self.names)
+            if n <= 1 << 16:   # (numpy's stable sort of 16-bit keys is a radix sort: 10x faster than of 32-bit keys)
+                order = np.argsort(self.coo_name.astype(np.uint16), kind='stable')
+            else:
+                order = np.argsort(self.coo_name, kind='stable')     # by name, cells ascending inside
+            self._starts = np.searchsorted(self.coo_name[order], np.arange(n + 1))
+            self._by_name = order
 
     def __len__(self):
         return len(self.names)
@@ -28,9 +39,12 @@ class ScResult(Mapping):
         return iter(self.names)
 
     def __contains__(self, key):
+        if self._index is None:
+            self._index = {n: i for i, n in enumerate(self.names)}
         return key in self._index
 
     def __getitem__(self, key):
+        self._group()
         i = self._index[key]
         d = self._cache.get(i)
         if d is None:
