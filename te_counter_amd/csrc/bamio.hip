@@ -113,13 +113,8 @@ struct RawBlock {
 
 // One raw-DEFLATE block body -> exactly isize bytes.  The fast decoder first (inflate_fast.h, ~2x
 // zlib on BAM payloads); anything it refuses goes to zlib, whose verdict is final.
-// TEC_INFLATE=zlib forces zlib.
 bool inflate_one(const uint8_t* in, size_t in_len, uint8_t* out, size_t isize, tec_inflate::Tables* tabs) {
-    static const bool force_zlib = [] {
-        const char* e = getenv("TEC_INFLATE");
-        return e && !strcmp(e, "zlib");
-    }();
-    if (!force_zlib && tec_inflate::inflate_block(in, in_len, out, isize, tabs)) return true;
+    if (tec_inflate::inflate_block(in, in_len, out, isize, tabs)) return true;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -467,11 +462,19 @@ namespace {
 bool bgzf_header_at(const uint8_t* m, size_t len, size_t o, size_t* bsize) {
     if (len - o < 18) return false;
     const uint8_t* h = m + o;
-    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || h[3] != 4 || h[10] != 6 || h[11] != 0 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 ||
-        h[15] != 0)
-        return false;
-    *bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
-    return *bsize >= 26 && o + *bsize <= len;
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || h[3] != 4) return false;
+    // the BC subfield anywhere in the extra field (htslib writes it alone; the format allows others around it)
+    const size_t xlen = h[10] | (h[11] << 8);
+    if (xlen < 6 || len - o < 12 + xlen) return false;
+    long bs = -1;
+    for (size_t x = 0; x + 4 <= xlen;) {
+        const size_t slen = h[12 + x + 2] | (h[12 + x + 3] << 8);
+        if (h[12 + x] == 'B' && h[12 + x + 1] == 'C' && slen == 2 && x + 6 <= xlen) bs = h[12 + x + 4] | (h[12 + x + 5] << 8);
+        x += 4 + slen;
+    }
+    if (bs < 0) return false;
+    *bsize = (size_t)bs + 1;
+    return *bsize >= 20 + xlen && o + *bsize <= len;
 }
 size_t find_bgzf_block(const uint8_t* m, size_t len, size_t from) {
     for (size_t o = from; o + 18 <= len; ++o) {
@@ -597,6 +600,7 @@ static int bam_open_impl(const char* path, int n_threads, uint64_t range_begin, 
             r->buf_pos = 0;
             r->wblocks.clear();
             r->eof = false;
+            r->owned_done = false;  // (reading the header of a file of a few blocks has already met the end of the file)
             r->raw_pos = find_bgzf_block(r->map, r->map_len, (size_t)std::min<uint64_t>(range_begin, r->map_len));
             std::vector<uint32_t> lens(r->ref_lens);
             size_t x = 0;

@@ -1055,22 +1055,12 @@ int tec_bulk_init(tec_ctx* ctx) {
     ctx->rec_ne_wanted = 3;  // inline entries per bin record (32-byte records)
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 0;
-#ifdef TEC_DIAGNOSTICS
-    // ablation builds only (make EXTRA=-DTEC_DIAGNOSTICS): 2 no counting, 4 no tests, 8 no gathers --
-    // results are WRONG by construction, so a normal build ignores the variable
-    e = getenv("TEC_ABLATE");
-    ctx->ablate = e ? (atoi(e) & 62) : 0;
-#else
     ctx->ablate = 0;
-#endif
-    e = getenv("TEC_LDS_KB");  // tuning knob: LDS histogram bytes per workgroup
-    ctx->lds_bytes = e && atoi(e) > 0 && atoi(e) <= 154 ? (uint32_t)atoi(e) * 1024u : 0u;  // 0 = automatic
-    e = getenv("TEC_TIME_EVERY");  // experiment: timestamp only every k-th count launch (0 = never)
-    ctx->time_every = e ? atoi(e) : 1;
+    ctx->lds_bytes = 0u;  // LDS histogram bytes per workgroup: automatic
+    ctx->time_every = 1;
     e = getenv("TEC_SPILL");  // 0: names beyond the LDS histogram are counted with global atomics (the round-1 path)
     ctx->spill_enabled = !(e && atoi(e) == 0);
-    e = getenv("TEC_SPAN_DIV");  // tuning knob: spans per workgroup
-    ctx->span_div = e && atoi(e) > 0 ? atoi(e) : 8;
+    ctx->span_div = 8;  // spans per workgroup
     return TEC_OK;
 }
 

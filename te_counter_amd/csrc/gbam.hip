@@ -57,8 +57,8 @@ constexpr uint32_t kSegShift = 16;
 constexpr uint32_t kSeg = 1u << kSegShift;
 constexpr uint32_t kMaxRecPerSeg = kSeg / 36u + 2u;  // a record is at least 36 bytes with its size field
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-const bool kTrace = getenv("TEC_GBAM_TRACE") != nullptr;  // staging-thread phase times on stderr
 constexpr size_t kCarryMax = 64u << 20;  // longest record tail carried from one chunk to the next
+constexpr int kInflLanes = 256;          // lanes per workgroup of the phase-1 kernel: 640 bytes of LDS each = all 160 KiB of a CU
 constexpr int kStreams = 5;              // inflate streams (slot i launches on stream i % kStreams)
 constexpr int kDepth = 8;                // chunks in flight: being staged, inflating or being consumed (chunk k lives in slot k % kDepth)
 constexpr size_t kScratchPerWave = 64u * (tec_ginf::kLongSymsPerLane * 2u + tec_ginf::kLenWords * 8u);  // global scratch of the inflate kernel
@@ -462,7 +462,6 @@ struct tec_gbam : GbamBuffers {
     uint32_t chunk_blocks = 16384;  // 32 workgroups of 512 lanes; (stream offsets are 32-bit: <= 4 GiB inflated)
     size_t piece_bytes = 256u << 20;  // pinned staging ring: two buffers of this size
     int read_threads = 8;
-    int infl_lanes = 256;  // lanes per workgroup of the inflate kernel (640 bytes of LDS each)
     // run state
     uint64_t n_records = 0;   // owned records delivered so far
     bool start_known = false;
@@ -556,7 +555,6 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         if (pc.busy) {
             (void)hipEventSynchronize(pc.done);
             pc.busy = false;
-            if (kTrace) fprintf(stderr, "[stage] waited %.1f ms for a piece's H2D copy\n", (now_s() - t0) * 1e3);
         }
         const size_t win = (size_t)std::min<uint64_t>(g->piece_bytes, g->file_size - base);
         if (win + 32 > pc.cap) {
@@ -610,7 +608,6 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             if (!v) st->error = "read error on the alignment file";
         memset(r.pc->p + r.win, 0, 32);
         g->t_stage_read += now_s() - r.t0;
-        if (kTrace) fprintf(stderr, "[stage] pread %zu MB, ready %.1f ms after it was asked for\n", r.win >> 20, (now_s() - r.t0) * 1e3);
     };
     size_t o = 0;  // bytes of the chunk that are parsed and on their way
     uint64_t infl = 0;
@@ -629,7 +626,6 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
         if (!to_eof && o + win + kOverlap < cap_bytes && cur.base + cur.win < limit + kOverlap) {
             if (!begin_read(nxt, cur.base + cur.win - kOverlap)) break;
         }
-        const double t_parse = now_s();
         size_t q = 0;  // whole blocks of this piece
         while (st->desc.size() < max_blocks) {
             if (off + o + q >= limit) {
@@ -656,7 +652,6 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             infl += isize;
             q += bsize;
         }
-        if (kTrace) fprintf(stderr, "[stage] header walk %.1f ms\n", (now_s() - t_parse) * 1e3);
         if (!st->error.empty()) break;
         if (q) {
             e = hipMemcpyAsync(st->d_comp.as<uint8_t>() + o, pb, q + tec_ginf::kInPad, hipMemcpyHostToDevice, cp);
@@ -683,7 +678,6 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
     }
     if (cur.active) end_read(cur, false);
     if (nxt.active) end_read(nxt, false);
-    if (kTrace) fprintf(stderr, "[stage] chunk at %llu: %zu bytes, %zu blocks\n", (unsigned long long)off, o, st->desc.size());
     st->bytes = o;
     st->inflated = infl;
     if (!st->desc.empty()) g->mean_block_bytes = (double)o / (double)st->desc.size();
@@ -820,8 +814,7 @@ int launch_inflate(tec_gbam* g, Staged* st, int buf, int lane_stream) {
             st->d_desc.as<BlockDesc>(), nb, st->d_comp.as<uint8_t>(), infl.as<uint8_t>() + kCarryMax, st->d_syms.as<uint16_t>(), d_nfailed,
             d_nfailed + 16, pool.as<uint32_t>(), n_pages, st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
     };
-    if (g->infl_lanes == 128) p1(ginflate_kernel<128>, 128);
-    else p1(ginflate_kernel<256>, 256);
+    p1(ginflate_kernel<kInflLanes>, (uint32_t)kInflLanes);
     G_HIP(hipGetLastError());
     gresolve_kernel<<<(nb + 3u) / 4u, 256, 0, si>>>(st->d_desc.as<BlockDesc>(), nb, infl.as<uint8_t>() + kCarryMax, pool.as<uint32_t>(),
                                                    st->d_pages.as<uint32_t>(), st->d_ntok.as<uint32_t>());
@@ -1078,11 +1071,6 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
         const long kb = atol(e);
         if (kb >= 192 && kb <= (2047l << 10)) g->piece_bytes = (size_t)kb << 10;
     }
-    if (const char* e = getenv("TEC_GBAM_READ_THREADS")) {
-        const long nt = atol(e);
-        if (nt >= 1 && nt <= 64) g->read_threads = (int)nt;
-    }
-    if (const char* e = getenv("TEC_GBAM_LANES")) g->infl_lanes = atoi(e);
     if (const char* e = getenv("TEC_GBAM_CHUNK_BLOCKS")) {
         const long nb = atol(e);
         if (nb >= 1 && nb <= 65536) g->chunk_blocks = (uint32_t)nb;
@@ -1117,11 +1105,8 @@ extern "C" int tec_gbam_open(tec_ctx* ctx, const char* path, uint64_t range_begi
     if (e == hipSuccess) e = g->d_reflen.reserve(std::max<size_t>(1, (size_t)n_ref) * 4);
     if (e == hipSuccess && n_ref) e = hipMemcpy(g->d_reflen.p, g->ref_lens.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess)  // (more than 64 KiB of dynamic LDS has to be asked for)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                128 * (int)tec_ginf::kEntriesPerLane * 2);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                256 * (int)tec_ginf::kEntriesPerLane * 2);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ginflate_kernel<kInflLanes>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kInflLanes * (int)tec_ginf::kEntriesPerLane * 2);
     if (e != hipSuccess) {
         close(g->fd);
         g->d_reflen.release();

@@ -102,15 +102,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (bin_shift != 0 && (bin_shift < kMinShift || bin_shift > kMaxShift))
         return tec_fail(ctx, TEC_EINVAL, "tec_index_build: bin_shift %d outside [%d, %d]", bin_shift, kMinShift, kMaxShift);
 
-    // TEC_INDEX_TIMING=1: phase times of the build on stderr
-    const bool timing = getenv("TEC_INDEX_TIMING") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto mark = [&](const char* what) {
-        if (!timing) return;
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[tec_index_build] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
-        t_prev = t;
-    };
+    auto mark = [&](const char*) {};  // (phase boundaries of the build; a timing build prints them)
     // pass 1: validate, per-chromosome extent, entry totals for every candidate shift
     std::vector<int64_t> chrom_hi(n_chrom, -1);
     uint64_t entries_at[kMaxShift + 1] = {0};
@@ -317,14 +309,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     }
     void* blob = nullptr;
     {
-        // experiment knob: TEC_INDEX_MEM=uncached|finegrained allocates the index with that MTYPE
-        const char* m = getenv("TEC_INDEX_MEM");
-        if (m && !strcmp(m, "uncached"))
-            TEC_HIP(ctx, hipExtMallocWithFlags(&blob, total, hipDeviceMallocUncached));
-        else if (m && !strcmp(m, "finegrained"))
-            TEC_HIP(ctx, hipExtMallocWithFlags(&blob, total, hipDeviceMallocFinegrained));
-        else
-            TEC_HIP(ctx, hipMalloc(&blob, total));
+        TEC_HIP(ctx, hipMalloc(&blob, total));
     }
     char* p = static_cast<char*>(blob);
     mark("bin records + device malloc");

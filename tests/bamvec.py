@@ -58,14 +58,25 @@ def header(refs):
     return h
 
 
-def bgzf_block(data, level=6):
-    if level < 0:  # a stored deflate block, by hand
+def bgzf_block(data, level=6, wbits=15, memlevel=8, strategy=0, extra_before=b'', extra_after=b''):
+    """One BGZF block.  level < 0: a stored deflate block, by hand.  extra_before / extra_after: other gzip extra
+    subfields (SI1 SI2 SLEN data) around the BC subfield -- the BGZF section of the SAM specification allows them."""
+    assert len(data) <= 65536, 'a BGZF block holds at most 64 KiB'
+    if level < 0:
         c = b'\x01' + struct.pack('<HH', len(data), len(data) ^ 0xFFFF) + data
     else:
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        co = zlib.compressobj(level, zlib.DEFLATED, -wbits, memlevel, strategy)
         c = co.compress(data) + co.flush()
-    return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(c) + 25) + c +
-            struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data)))
+    xlen = 6 + len(extra_before) + len(extra_after)
+    bsize = 12 + xlen + len(c) + 8
+    if bsize > 65536:
+        raise ValueError('BGZF block larger than 64 KiB')
+    return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff' + struct.pack('<H', xlen) + extra_before + b'BC\x02\x00' +
+            struct.pack('<H', bsize - 1) + extra_after + c + struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def subfield(si, data):
+    return si + struct.pack('<H', len(data)) + data
 
 
 BGZF_EOF = bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000')
@@ -79,6 +90,28 @@ def write_blocks(path, payload, cuts, level=6, empty_after=()):
             fh.write(bgzf_block(payload[edges[k]:edges[k + 1]], level))
             if k in empty_after:
                 fh.write(bgzf_block(b'', level))
+        fh.write(BGZF_EOF)
+
+
+def write_blocks_varied(path, payload, cuts, seed, empty_after=()):
+    """As write_blocks, but every block is compressed with its own zlib settings -- level 0..9, history window 2^9..2^15,
+    memLevel 1..9, every strategy -- and a third of the blocks carry foreign extra subfields in front of and/or behind BC."""
+    import random
+    rnd = random.Random(seed)
+    edges = [0] + sorted(cuts) + [len(payload)]
+    with open(path, 'wb') as fh:
+        for k in range(len(edges) - 1):
+            kind = rnd.randrange(6)
+            before = subfield(b'XA', bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 9)))) if kind in (1, 3) else b''
+            after = subfield(b'RA', bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 20)))) if kind in (2, 3) else b''
+            try:
+                blk = bgzf_block(payload[edges[k]:edges[k + 1]], rnd.randrange(10), rnd.randrange(9, 16), rnd.randrange(1, 10),
+                                 rnd.randrange(5), before, after)
+            except ValueError:  # (a full 0xFF00-byte payload that these settings do not shrink below 64 KiB)
+                blk = bgzf_block(payload[edges[k]:edges[k + 1]], 6, extra_before=before)
+            fh.write(blk)
+            if k in empty_after:
+                fh.write(bgzf_block(b'', rnd.randrange(10), extra_before=before))
         fh.write(BGZF_EOF)
 
 
@@ -151,6 +184,49 @@ def every_cigar_op_and_aux_type():
         (record(-1, -1, 0, 4, 'cg_unplaced_long_umi', [(12, 4), (7, 3)], l_seq=12,
                 aux_bytes=aux('CG', 'B', [(5 << 4) | 0, (3 << 4) | 0], 'I') + aux('CB', 'Z', 'Q') + aux('UB', 'Z', 'U' * 25)),
          {'tid': -1, 'pos': -1, 'end': 6, 'flag': 4, 'mapq': 0, 'cb': 'Q', 'ub': '', 'tf': 1 | 2 | 8}),
+    ]
+    payload = header(refs)
+    hdr_len = len(payload)
+    starts = []
+    for rb, _ in rows:
+        starts.append(len(payload))
+        payload += rb
+    return payload, [w for _, w in rows], hdr_len, starts
+
+
+def files_never_seen():
+    """Shapes a decoder meets in files from other writers: a 254-character read name, records without sequence
+    (l_seq = 0, with and without CIGAR), the smallest record there is, a mapped record without CIGAR, aux fields
+    of every type BEHIND CB / UB, CB / UB as the very last bytes of a record, a read long enough to fill a maximal
+    0xFF00-byte BGZF block on its own, and names that end in '/' or are nothing but '/'."""
+    refs = [('chr1', 100000), ('chrUn_KI270742v1', 186739), ('chr2', 50000)]
+    zoo = (aux('XA', 'A', 'q') + aux('Xc', 'c', -5) + aux('XC', 'C', 200) + aux('Xs', 's', -3000) + aux('XS', 'S', 60000) +
+           aux('NH', 'i', -7) + aux('XI', 'I', 4000000000) + aux('Xf', 'f', 1.5) + aux('RG', 'Z', 'grp:1') + aux('XH', 'H', '1AE301') +
+           aux('Bc', 'B', [-1, 2], 'c') + aux('BS', 'B', [300, 4], 'S') + aux('Bf', 'B', [0.5, 2.0], 'f') + aux('Be', 'B', [], 'C'))
+    long_name = 'n' * 250 + '/1xy'  # 254 characters: l_read_name = 255
+    rows = [
+        (record(0, 10, 30, 0, long_name, '10M', aux_bytes=aux('CB', 'Z', 'NAMECB') + aux('UB', 'Z', 'NAMEUB')),
+         {'tid': 0, 'pos': 10, 'end': 20, 'flag': 0, 'mapq': 30, 'cb': 'NAMECB', 'ub': 'NAMEUB', 'tf': 3}),
+        (record(0, 30, 30, 0, 'noseq_cigar', '7M2D3M', l_seq=0, aux_bytes=aux('CB', 'Z', 'A') + aux('UB', 'Z', 'C')),
+         {'tid': 0, 'pos': 30, 'end': 42, 'flag': 0, 'mapq': 30, 'cb': 'A', 'ub': 'C', 'tf': 3}),
+        (record(0, 40, 30, 0, 'noseq_nocigar', '', l_seq=0),
+         {'tid': 0, 'pos': 40, 'end': NO_END, 'flag': 0, 'mapq': 30, 'cb': '', 'ub': '', 'tf': 0}),
+        (record(-1, -1, 0, 4, 'x', '', l_seq=0),  # 34 bytes behind the size field: nothing is smaller
+         {'tid': -1, 'pos': -1, 'end': NO_END, 'flag': 4, 'mapq': 0, 'cb': '', 'ub': '', 'tf': 0}),
+        (record(2, 49990, 0, 16, 'mapped_nocigar', '', l_seq=20, aux_bytes=aux('UB', 'Z', 'ONLYUB')),
+         {'tid': 2, 'pos': 49990, 'end': NO_END, 'flag': 16, 'mapq': 0, 'cb': '', 'ub': 'ONLYUB', 'tf': 2}),
+        (record(1, 500, 60, 0, 'tags_behind', '50M', aux_bytes=aux('CB', 'Z', 'ACGTACGTACGTACGT-1') + aux('UB', 'Z', 'AACCGGTTAACC') + zoo),
+         {'tid': 1, 'pos': 500, 'end': 550, 'flag': 0, 'mapq': 60, 'cb': 'ACGTACGTACGTACGT-1', 'ub': 'AACCGGTTAACC', 'tf': 3}),
+        (record(1, 600, 60, 0, 'tags_between', '50M', aux_bytes=aux('UB', 'Z', 'UFIRST') + zoo + aux('CB', 'Z', 'CLAST')),
+         {'tid': 1, 'pos': 600, 'end': 650, 'flag': 0, 'mapq': 60, 'cb': 'CLAST', 'ub': 'UFIRST', 'tf': 3}),
+        (record(0, 1000, 44, 0, 'fills_a_block/2', '43000M', aux_bytes=aux('CB', 'Z', 'BIG') + aux('UB', 'Z', 'READ')),
+         {'tid': 0, 'pos': 1000, 'end': 44000, 'flag': 0, 'mapq': 44, 'cb': 'BIG', 'ub': 'READ', 'tf': 3}),
+        (record(0, 2000, 20, 0, 'ends_in_slash/', '5M'),
+         {'tid': 0, 'pos': 2000, 'end': 2005, 'flag': 0, 'mapq': 20, 'cb': '', 'ub': '', 'tf': 0}),
+        (record(0, 2100, 20, 0, '/', '5M', aux_bytes=aux('CB', 'Z', '') + aux('UB', 'Z', '')),  # empty tag strings are present tags
+         {'tid': 0, 'pos': 2100, 'end': 2105, 'flag': 0, 'mapq': 20, 'cb': '', 'ub': '', 'tf': 3}),
+        (record(2, 0, 255, 0x900, 'first_base', '1M', aux_bytes=aux('CR', 'Z', 'R') + aux('UR', 'Z', 'S')),
+         {'tid': 2, 'pos': 0, 'end': 1, 'flag': 0x900, 'mapq': 255, 'cb': 'R', 'ub': 'S', 'tf': 3}),
     ]
     payload = header(refs)
     hdr_len = len(payload)

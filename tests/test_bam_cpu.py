@@ -195,6 +195,44 @@ def test_every_cigar_op_every_aux_type_and_block_layouts(tmp_path, level):
         assert got['qkey'][0] != got['qkey'][1]
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_files_from_other_writers(tmp_path, seed):
+    """Record shapes and BGZF blocks this repo's writer never produces (tests/bamvec.py, files_never_seen and
+    write_blocks_varied): 254-character names, l_seq = 0, the 34-byte record, mapped without CIGAR, every aux type
+    behind CB/UB, a read that fills a maximal block; every block with its own zlib level / window / memLevel / strategy
+    and foreign gzip extra subfields around BC; htslib's 0xFF00-byte blocks and tiny ones with empty blocks between."""
+    import bamvec
+    from te_counter_amd import dist
+    payload, want, hdr_len, starts = bamvec.files_never_seen()
+    layouts = [(list(range(0xff00, len(payload), 0xff00)), ()), ([hdr_len, hdr_len + 30000], (0,)), (sorted(set(starts[1:])), (2, 3)),
+               (list(range(hdr_len, len(payload), 4001)), (1, 5, 6)), ([starts[3] + 2, starts[3] + 33, starts[4] + 1], (0, 1, 2))]
+    for cuts, empties in layouts:
+        p = tmp_path / 'unseen.bam'
+        bamvec.write_blocks_varied(str(p), payload, cuts, seed, empty_after=empties)
+        for threads in (1, 3):
+            got, names = _decode_all(p, threads=threads, batch_size=4)
+            assert names == ['chr1', 'chrUn_KI270742v1', 'chr2']
+            bamvec.check_rows(got, want)
+        assert got['qkey'][9] == got['qkey'][3]          # '/' and a name without '/': the key is the (empty) text before the last '/'
+        assert got['qkey'][8] != got['qkey'][9] and got['qkey'][0] != got['qkey'][8]
+        # byte ranges: a range start is found by the general BGZF header form too (extra subfields around BC)
+        size = os.path.getsize(str(p))
+        for world in (2, 3):
+            rows, reports = [], []
+            for r in range(world):
+                src = bam.BamSource(str(p), byte_range=bam.byte_range(size, r, world), batch_size=4, threads=2)
+                parts = list(src._batches(want_tags=True))
+                first, end, has = src.range_tokens()
+                src.close()
+                n = sum(len(b) for b in parts)
+                reports.append({'has_records': has and n > 0, 'first_token': first, 'end_token': end, 'n_records': n})
+                rows += parts
+            if rows:
+                ranged = {k: np.concatenate([getattr(b, k) for b in rows]) for k in ('tid', 'pos', 'end', 'flag', 'mapq', 'cb24', 'ub24', 'tagflags')}
+                bamvec.check_rows(ranged, want)
+            dist.check_ranges(reports, size)
+
+
 def test_hand_assembled_vectors_byte_ranges(tmp_path):
     """The same records cut into 37-byte BGZF blocks and read as 1..9 byte ranges: every range owns the
     records that start in its blocks, nothing is lost or doubled, tokens chain."""
@@ -256,3 +294,20 @@ def test_first_range_without_records_still_pins_the_first_record(tmp_path):
             with pytest.raises(RuntimeError):
                 dist.check_ranges(forged, size)
     assert seen_empty_first and hdr_len > size // 4
+
+
+def test_thread_count_from_the_environment(tmp_path, monkeypatch):
+    """TEC_BAM_THREADS sets the host decoder's threads when the caller passes none: same rows with 1, 3 and the default."""
+    recs = _records(3000)
+    path = str(tmp_path / 't.bam')
+    bam.write_bam(path, _refs(recs), recs, block_bytes=900)
+    ref = None
+    for value in (None, '1', '3'):
+        if value is None:
+            monkeypatch.delenv('TEC_BAM_THREADS', raising=False)
+        else:
+            monkeypatch.setenv('TEC_BAM_THREADS', value)
+        got, _ = _decode_all(path, threads=0, batch_size=257)
+        cols = [got[k].tolist() for k in ('tid', 'pos', 'end', 'flag', 'mapq', 'qkey')]
+        ref = ref or cols
+        assert cols == ref and len(cols[0]) == len(recs)

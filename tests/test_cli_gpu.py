@@ -191,3 +191,33 @@ def test_multi_rank_cli_bulk_and_single_cell(nproc, tmp_path):
     _launch(argv, nproc, tmp_path)
     assert open(out).read() == g['expected']['tsv']
     assert open(out.replace('.tsv', '.barcode_freq.tsv')).read() == g['expected']['barcode_freq']
+
+
+def test_host_decoder_switch_and_index_threads(tmp_path, monkeypatch):
+    """TEC_DECODER=cpu sends a BAM file through the host decoder, TEC_INDEX_THREADS sets the threads of the index
+    build: the TSV is the reference's either way."""
+    g = load_golden('bulk_pe_rand12')
+    idx, aln = _prepare(g, tmp_path)
+    outs = []
+    for env in ({}, {'TEC_DECODER': 'cpu'}, {'TEC_INDEX_THREADS': '1'}, {'TEC_DECODER': 'cpu', 'TEC_INDEX_THREADS': '3'}):
+        for k in ('TEC_DECODER', 'TEC_INDEX_THREADS'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = str(tmp_path / ('o%d.tsv' % len(outs)))
+        cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom', '-q', str(g['params']['q'])])
+        outs.append(open(out).read())
+    assert all(o == g['expected']['tsv'] for o in outs)
+
+
+def test_bench_rehearsal_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` from a bare interpreter starts its two ranks itself; TEC_BENCH_BACKEND=gloo lets them
+    share the one GPU of this box.  One JSON line, whole-job value over both ranks."""
+    import json
+    env = dict(os.environ, TEC_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--records', '4000000',
+                        '--scale', '0.05', '--cpu-sample', '0'], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['scaling'] == 'weak' and line['value'] > 0

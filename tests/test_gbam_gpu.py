@@ -202,6 +202,26 @@ def test_specification_vectors(eng, tmp_path):
                 dist.check_ranges([r for r, _ in parts], size)
 
 
+@pytest.mark.parametrize('seed', [1, 2])
+def test_files_from_other_writers(eng, tmp_path, seed):
+    """tests/bamvec.py files_never_seen / write_blocks_varied (254-character names, l_seq = 0, the 34-byte record, every
+    aux type behind CB/UB, a read that fills a block; per-block zlib level / window / memLevel / strategy, foreign gzip
+    extra subfields): the GPU decoder delivers the expected rows, agrees with the host decoder, and so do byte ranges."""
+    payload, want, hdr_len, starts = bamvec.files_never_seen()
+    p = str(tmp_path / 'unseen.bam')
+    for cuts, empties in [(list(range(0xff00, len(payload), 0xff00)), ()), (sorted(set(starts[1:])), (2, 3)),
+                          (list(range(hdr_len, len(payload), 4001)), (1, 5, 6)), ([starts[3] + 2, starts[3] + 33, starts[4] + 1], (0, 1, 2))]:
+        bamvec.write_blocks_varied(p, payload, cuts, seed, empty_after=empties)
+        rep, got = gpu_decode(eng, p)
+        bamvec.check_rows(got, want)
+        same(got, host_decode(p))
+        size = os.path.getsize(p)
+        for world in (2, 3):
+            parts = [gpu_decode(eng, p, bam.byte_range(size, r, world)) for r in range(world)]
+            bamvec.check_rows({k: np.concatenate([a[k] for _, a in parts]) for k in FIELDS}, want)
+            dist.check_ranges([r for r, _ in parts], size)
+
+
 def test_corrupt_and_truncated_files(eng, tmp_path):
     _, path, _ = _synthetic(tmp_path, 'illumina', 20_000)
     raw = open(path, 'rb').read()

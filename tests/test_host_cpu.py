@@ -201,3 +201,29 @@ def test_whitelist_loader_equals_the_reference_expression(tmp_path):
     p.write_text('A' * 25 + '\n')
     with pytest.raises(ValueError):
         reads.load_whitelist(str(p))
+
+
+def test_documented_environment_variables():
+    """INTEGRATION.md section 4 lists exactly the variables the sources read: every getenv() of the library and every
+    TEC_* lookup of the package, bench.py and the tools' rank set-up."""
+    import glob
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, 'te_counter_amd', 'csrc', '*')):
+        read |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(ROOT, 'te_counter_amd', '*.py')) + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, 'tools', 'bench_sc.py')]:
+        read |= set(re.findall(r"environ(?:\.get|\.setdefault)?[\[(]'((?:TEC|GPU)_[A-Z_0-9]+)'", open(f).read()))
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    table = doc[doc.index('## 4. Environment variables'):]
+    documented = set(re.findall(r'`((?:TEC|GPU)_[A-Z_0-9]+)`', table.split('| variable |')[1]))
+    assert read == documented, (sorted(read - documented), sorted(documented - read))
+
+
+def test_no_torch_switch():
+    """TEC_NO_TORCH=1: the library loads without importing torch (single-process runs)."""
+    import subprocess
+    import sys
+    code = "import sys; from te_counter_amd import _lib; _lib.load(); print('torch' in sys.modules)"
+    for value, want in (('1', 'False'), ('', 'True')):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                           env=dict(os.environ, TEC_NO_TORCH=value))
+        assert r.returncode == 0 and r.stdout.strip() == want, (value, r.stdout, r.stderr[-500:])

@@ -69,6 +69,29 @@ def test_matches_zlib(level, strategy, decoder):
 
 
 @DECODERS
+def test_every_history_window_and_memory_level(decoder):
+    """Streams from compressors with a smaller history window (2^9 .. 2^15 bytes) and every memLevel (which sets how
+    many symbols a deflate block holds: memLevel 1 cuts a 64 KiB payload into some 250 deflate blocks, each with its
+    own code tables), every strategy: what other BGZF writers may be configured to emit."""
+    rng = np.random.default_rng(21)
+    recs = bytearray()
+    for i in range(330):
+        recs += b'\x10\x01\x00\x00' + int(i * 37).to_bytes(4, 'little') + b'A00123:45:HXX:1:%d:%d\x00' % (1100 + i, i * 7)
+        recs += bytes(rng.integers(0, 4, 50, dtype=np.uint8) * 17) + bytes(rng.choice([2, 12, 23, 37], 100).astype(np.uint8)) + b'NHC\x01HIC\x01'
+    payloads = [bytes(recs)[:65280], bytes(rng.integers(0, 256, 20000, dtype=np.uint8)) + bytes(recs)[:30000], b'ab' * 30000]
+    k = 0
+    for wbits in range(9, 16):
+        for memlevel in (1, 2, 5, 8, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                data = payloads[k % len(payloads)]
+                co = zlib.compressobj(1 + k % 9, zlib.DEFLATED, -wbits, memlevel, strategy)
+                comp = co.compress(data) + co.flush()
+                rc, got = _inflate(comp, len(data), decoder, shift=k % 16)
+                assert rc == 0 and got == data, (wbits, memlevel, strategy)
+                k += 1
+
+
+@DECODERS
 def test_multi_block_streams(decoder):
     rng = np.random.default_rng(9)
     for _ in range(20):
