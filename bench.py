@@ -526,7 +526,7 @@ def single_cell(ann, eng, records):
     arrays, wl, tables = synth.make_sc_arrays(ann, records, n_cells=10000, seed=2004)
     gen_s = time.time() - t0
     n = len(arrays['pos'])
-    bench_sc.run(eng, {k: v[:1 << 20] for k, v in arrays.items()}, wl, tables, 10000, False, 10_000_000)  # warm-up
+    bench_sc.run(eng, {k: v[:1 << 23] for k, v in arrays.items()}, wl, tables, 10000, False, 10_000_000)  # warm-up: two batches of the run's size (the context keeps its staging ring and survivor arrays)
     out, st, t, _ = bench_sc.run(eng, arrays, wl, tables, 10000, False, 10_000_000)
     gpu_ms = eng.sc_gpu_ms
     alg = 32.0 * n  # 15 B + cb 8 + ub 8 + ub_len 1 per record

@@ -214,11 +214,15 @@ typedef struct tec_sc_stats_t {
  * string c, or -1 (te_count.py:614); class_skip[c] = '_' in c or 'alt' in c (te_count.py:432). */
 int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n_whitelist, const uint8_t* whitelist24,
                  uint64_t bundle_keys, uint32_t n_class, const int32_t* class_index_chrom, const uint8_t* class_skip);
-/* Host SoA batch, in file order.  Synchronous: the buffers are free on return. */
+/* Host SoA batch, in file order.  The caller's buffers are free on return (they have been copied into a pinned
+ * staging ring); the copy to HBM and the filter / compaction kernels are queued behind earlier batches and run
+ * while the caller prepares the next one.  Any later tec_sc_* call that needs their result waits for them. */
 int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const int32_t* pos, const int32_t* end,
                   const uint16_t* flag, const uint8_t* mapq, const uint8_t* cb24, const uint8_t* ub24,
                   const uint8_t* tagflags);
-/* Same, for a batch that is already resident in HBM (device pointers). */
+/* Same, for a batch that is already resident in HBM (device pointers).  The kernels are QUEUED on the context's
+ * compute stream: the arrays must stay untouched until work queued on that stream BEHIND this call has started
+ * (libtecount's own decoder reuses them from that stream only), or until tec_sc_survivors / tec_sc_part1* returns. */
 int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
                          const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb24, const uint8_t* d_ub24,
                          const uint8_t* d_tagflags);

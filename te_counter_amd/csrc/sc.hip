@@ -29,6 +29,10 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
+#include <utility>
+#include <vector>
 
 #include "tecount_internal.h"
 
@@ -63,7 +67,7 @@ struct dvec {
     }
 };
 
-enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_LONGUMI, ST_OR0, ST_OR1, ST_OR2, ST_NOSTRAND, ST_N };
+enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_LONGUMI, ST_OR0, ST_OR1, ST_OR2, ST_NLIVE, ST_NOSTRAND, ST_N };  // ST_NLIVE: survivors so far (the scatter kernel's output cursor)
 
 }  // namespace
 
@@ -82,7 +86,15 @@ struct ScBuffers {
     dvec<unsigned long long> stat;
     // batch temporaries
     dvec<uint32_t> b_live, b_scan, b_bcid;
-    dvec<char> b_in, tmp;
+    dvec<char> b_in, b_in2, tmp;  // two device staging buffers: batch k + 1 is copied while batch k is filtered
+    // host batches travel through a ring of three pinned buffers (worker threads copy the caller's arrays in, the copy
+    // stream takes them to HBM): pin_done[i] = slot i's copy to HBM has finished, in_free[j] = the ingest kernels have
+    // finished reading staging buffer j
+    char* pin[3] = {nullptr, nullptr, nullptr};
+    size_t pin_cap[3] = {0, 0, 0};
+    hipEvent_t pin_done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t in_free[2] = {nullptr, nullptr}, in_copied[2] = {nullptr, nullptr};
+    uint64_t n_submits = 0;
     // sorted views (part 1)
     dvec<uint32_t> perm, perm2, s_bcid, gid, s_epoch, headidx, cnt;
     dvec<unsigned long long> first_seen;
@@ -97,7 +109,19 @@ struct ScBuffers {
         wl.release(); wl_table.release(); cls_chrom.release(); cls_skip.release();
         bcid.release(); u0.release(); u1.release(); u2.release(); rec.release();
         klass.release(); left.release(); rite.release(); stat.release();
-        b_live.release(); b_scan.release(); b_bcid.release(); b_in.release(); tmp.release();
+        b_live.release(); b_scan.release(); b_bcid.release(); b_in.release(); b_in2.release(); tmp.release();
+        for (int i = 0; i < 3; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (pin_done[i]) (void)hipEventDestroy(pin_done[i]);
+            pin[i] = nullptr;
+            pin_cap[i] = 0;
+            pin_done[i] = nullptr;
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (in_free[i]) (void)hipEventDestroy(in_free[i]);
+            if (in_copied[i]) (void)hipEventDestroy(in_copied[i]);
+            in_free[i] = in_copied[i] = nullptr;
+        }
         perm.release(); perm2.release(); s_bcid.release(); gid.release(); s_epoch.release();
         headidx.release(); cnt.release(); first_seen.release(); k64a.release(); k64b.release();
         s_u0.release(); s_u1.release(); s_u2.release(); k32a.release(); k32b.release();
@@ -116,7 +140,9 @@ struct tec_sc_state : ScBuffers {
     uint64_t expected_records = 0;  // of the whole input, if the caller can tell (the BAM decoder can): sizes the survivor arrays
     uint32_t n_wl = 0, n_class = 0;
     uint32_t wl_mask = 0;
-    uint64_t n_live = 0, n_seen = 0;
+    uint64_t n_live = 0, n_seen = 0;  // n_live is behind the device's cursor while batches are in flight (sc_settle)
+    bool in_flight = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ingest_spans;  // stream time of the batches not yet added to gpu_ms
     uint32_t n_groups = 0, n_epochs = 1;
     bool part1_done = false, sorted = false;
     uint64_t rec_base = 0, max_rec = 0, n_marks = 0;  // global ordinal of this context's first record; largest ordinal anywhere
@@ -237,7 +263,7 @@ __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* _
     tally.end(dst);
 }
 
-__global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, uint64_t out_base, const uint32_t* __restrict__ live,
+__global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ live,
                                   const uint32_t* __restrict__ scan, const uint32_t* __restrict__ bcid_in,
                                   const int32_t* __restrict__ cls, const int32_t* __restrict__ pos,
                                   const int32_t* __restrict__ end, const uint16_t* __restrict__ flag,
@@ -247,7 +273,7 @@ __global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, uint64_t out_ba
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t a = 0, b = 0, c = 0;
     if (i < n && live[i]) {
-        const uint64_t o = out_base + scan[i];
+        const uint64_t o = *cursor + scan[i];
         const uint8_t* p = ub + 24 * i;
         a = load_be64(p);
         b = load_be64(p + 8);
@@ -282,6 +308,11 @@ __global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, uint64_t out_ba
         unsigned long long* g = &stat[ST_OR0 + threadIdx.x];
         if ((or_lds[threadIdx.x] & ~__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) atomicOr(g, or_lds[threadIdx.x]);
     }
+}
+
+// Behind the scatter of a batch: the output cursor moves on by the batch's survivors.
+__global__ void sc_advance_kernel(uint64_t n, const uint32_t* __restrict__ live, const uint32_t* __restrict__ scan, unsigned long long* cursor) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cursor += (unsigned long long)scan[n - 1] + live[n - 1];
 }
 
 template <class T>
@@ -680,6 +711,14 @@ static void sc_park(tec_ctx* ctx) {
     tec_sc_state* s = ctx->sc;
     if (!s) return;
     ctx->sc = nullptr;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->s_copy);  // a batch may still be on its way
+    (void)hipStreamSynchronize(ctx->s_compute);
+    for (auto& span : s->ingest_spans) {
+        (void)hipEventDestroy(span.first);
+        (void)hipEventDestroy(span.second);
+    }
+    s->ingest_spans.clear();
     if (ctx->sc_parked) {
         s->free_all();
     } else {
@@ -785,50 +824,113 @@ struct PhaseTimer {  // accumulates the stream time between construction and sto
     ~PhaseTimer() { stop(); }
 };
 
-// Filters + order-preserving compaction of one batch that is resident in HBM (te_count.py:394-433).
-// Returns after the batch has been consumed: the input buffers are free again.
+// Waits for the batches in flight and brings the host's view up to date: the survivor count from the device's cursor,
+// the stream time of the batches into gpu_ms.
+int sc_settle(tec_ctx* ctx, tec_sc_state* s) {
+    if (!s->in_flight && s->ingest_spans.empty()) return TEC_OK;
+    SC_HIP(hipStreamSynchronize(ctx->s_compute));
+    unsigned long long live = 0;
+    SC_HIP(hipMemcpy(&live, s->stat.p + ST_NLIVE, sizeof live, hipMemcpyDeviceToHost));
+    for (auto& span : s->ingest_spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, span.first, span.second) == hipSuccess) s->gpu_ms += ms;
+        (void)hipEventDestroy(span.first);
+        (void)hipEventDestroy(span.second);
+    }
+    s->ingest_spans.clear();
+    s->in_flight = false;
+    if (live >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
+    s->n_live = live;
+    return TEC_OK;
+}
+
+// Filters + order-preserving compaction of one batch that is resident in HBM (te_count.py:394-433), queued on the
+// compute stream: the caller's buffers are free once that stream has passed this point (`done`, if given, is recorded
+// there).  Nothing here waits for the GPU: where the survivors go is a cursor in device memory, and the survivor arrays
+// are sized for every record seen so far to survive.
 int sc_ingest(tec_ctx* ctx, tec_sc_state* s, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
-              const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb, const uint8_t* d_ub, const uint8_t* d_tf) {
+              const uint16_t* d_flag, const uint8_t* d_mapq, const uint8_t* d_cb, const uint8_t* d_ub, const uint8_t* d_tf,
+              hipEvent_t done) {
     hipStream_t st = ctx->s_compute;
+    const uint64_t need = s->n_seen + n;  // upper bound of the survivors after this batch
+    if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 records");
+    // growing a buffer frees memory that queued kernels may still use: settle first (rare: see the floor below)
+    const bool grow = n > s->b_live.cap || n > s->b_scan.cap || n > s->b_bcid.cap || need > s->bcid.cap;
+    if (grow) {
+        int rc = sc_settle(ctx, s);
+        if (rc) return rc;
+    }
     SC_HIP(s->b_live.reserve(n));
-    PhaseTimer timer(ctx, s);
     SC_HIP(s->b_scan.reserve(n));
     SC_HIP(s->b_bcid.reserve(n));
+    // survivor arrays: room for sixteen batches like this one (<= 128 M records) at the first allocation, doubling after
+    // that -- or, when the caller has said how many records the whole input holds, for all of them (+ 2 %): fresh device
+    // memory is scrubbed by the driver at ~9 ms per GB, and regrowth is a copy
+    size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);
+    if (s->expected_records > s->n_seen) floor = (size_t)std::min<uint64_t>(s->expected_records + s->expected_records / 50 + 4096, 0xFFFFFFF0ull);
+    const size_t used = (size_t)s->n_seen;  // (an upper bound of what is in use)
+    SC_HIP(s->bcid.reserve(need, true, std::min(used, s->bcid.cap), floor));
+    SC_HIP(s->u0.reserve(need, true, std::min(used, s->u0.cap), floor));
+    SC_HIP(s->u1.reserve(need, true, std::min(used, s->u1.cap), floor));
+    SC_HIP(s->u2.reserve(need, true, std::min(used, s->u2.cap), floor));
+    SC_HIP(s->rec.reserve(need, true, std::min(used, s->rec.cap), floor));
+    SC_HIP(s->klass.reserve(need, true, std::min(used, s->klass.cap), floor));
+    SC_HIP(s->left.reserve(need, true, std::min(used, s->left.cap), floor));
+    SC_HIP(s->rite.reserve(need, true, std::min(used, s->rite.cap), floor));
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, st);
     hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, d_cls, d_flag, d_mapq, d_cb, d_tf,
                        s->mapq_min, s->wl.p, s->wl_table.p, s->wl_mask, s->cls_skip.p, s->n_class, s->b_live.p, s->b_bcid.p,
                        s->stat.p);
     int rc = scan_u32(ctx, s, s->b_live.p, s->b_scan.p, n, false, rocprim::plus<uint32_t>());
     if (rc) return rc;
-    uint32_t last_scan = 0, last_live = 0;
-    SC_HIP(hipMemcpyAsync(&last_scan, s->b_scan.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_HIP(hipMemcpyAsync(&last_live, s->b_live.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_HIP(hipStreamSynchronize(st));
-    const uint64_t add = (uint64_t)last_scan + last_live;
-    const uint64_t need = s->n_live + add;
-    if (need >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_submit: more than 2^32 surviving records");
-    // survivor arrays: room for sixteen batches like this one (<= 128 M records) at the first allocation, doubling after that
-    // -- or, when the caller has said how many records the whole input holds, for this batch's survivor rate applied to
-    // all of them (+ 8 %): fresh device memory is scrubbed by the driver at ~9 ms per GB, and sixteen batches' worth is
-    // 6 GB for a file that is decoded in one 10 M-record chunk
-    size_t floor = (size_t)std::min<uint64_t>(16 * n, 128ull << 20);  // at most 6 GB up front
-    if (s->expected_records > s->n_seen && s->n_live == 0)
-        floor = (size_t)std::min<uint64_t>((uint64_t)((double)add / (double)n * (double)s->expected_records * 1.08) + 4096, 0xFFFFFFF0ull);
-    SC_HIP(s->bcid.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->u0.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->u1.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->u2.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->rec.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->klass.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->left.reserve(need, true, s->n_live, floor));
-    SC_HIP(s->rite.reserve(need, true, s->n_live, floor));
-    hipLaunchKernelGGL(sc_scatter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, s->n_live, s->b_live.p,
+    hipLaunchKernelGGL(sc_scatter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, s->stat.p + ST_NLIVE, s->b_live.p,
                        s->b_scan.p, s->b_bcid.p, d_cls, d_pos, d_end, d_flag, d_ub, s->stranded, s->bcid.p, s->u0.p, s->u1.p,
                        s->u2.p, s->rec.p, s->klass.p, s->left.p, s->rite.p, s->stat.p);
+    hipLaunchKernelGGL(sc_advance_kernel, dim3(1), dim3(64), 0, st, n, s->b_live.p, s->b_scan.p, s->stat.p + ST_NLIVE);
     SC_HIP(hipGetLastError());
-    SC_HIP(hipStreamSynchronize(st));  // the batch buffers are free again
-    s->n_live = need;
+    if (t0 && t1 && hipEventRecord(t1, st) == hipSuccess) {
+        s->ingest_spans.emplace_back(t0, t1);
+    } else {
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+    }
+    if (done) SC_HIP(hipEventRecord(done, st));
+    s->in_flight = true;
     s->n_seen += n;
     return TEC_OK;
+}
+
+// One column of a host batch on its way into the pinned slot.
+struct CopyJob {
+    char* dst;
+    const void* src;
+    size_t bytes;
+};
+void parallel_fill(const CopyJob& job, int threads) {
+    const size_t per = ((job.bytes + (size_t)threads - 1) / (size_t)threads + 4095) & ~size_t(4095);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const size_t o = per * (size_t)t;
+        if (o < job.bytes) pool.emplace_back([=] { memset(job.dst + o, 0, std::min(per, job.bytes - o)); });
+    }
+    for (auto& t : pool) t.join();
+}
+// `threads` workers, each copying its slice of every column (page-cache speed needs more than one core; a thread per
+// column and slice would spend more time starting threads than copying)
+void parallel_copy(const CopyJob* jobs, int n_jobs, int threads) {
+    auto work = [=](int t) {
+        for (int j = 0; j < n_jobs; ++j) {
+            const size_t per = ((jobs[j].bytes + (size_t)threads - 1) / (size_t)threads + 63) & ~size_t(63);
+            const size_t o = per * (size_t)t;
+            if (o < jobs[j].bytes) memcpy(jobs[j].dst + o, static_cast<const char*>(jobs[j].src) + o, std::min(per, jobs[j].bytes - o));
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads);
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
 }
 }  // namespace
 
@@ -843,25 +945,82 @@ extern "C" int tec_sc_submit(tec_ctx* ctx, uint64_t n, const int32_t* cls, const
         return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit: NULL array");
     if (n >= 0x7FFFFFFFull) return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit: batch too large");
     SC_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->s_compute;
-    // stage the batch: cls | pos | end | flag | mapq | tagflags | cb | ub
+#ifdef TEC_SC_TRACE
+    const auto te0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        fprintf(stderr, "[sc_submit]   %-22s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count());
+    };
+#else
+    auto lap = [](const char*) {};
+#endif
+    // the batch as one block: cls | pos | end | flag | mapq | tagflags | cb | ub
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t o_cls = 0, o_pos = o_cls + al(n * 4), o_end = o_pos + al(n * 4), o_flag = o_end + al(n * 4),
                  o_mq = o_flag + al(n * 2), o_tf = o_mq + al(n), o_cb = o_tf + al(n), o_ub = o_cb + al(n * 24),
                  total = o_ub + al(n * 24);
-    SC_HIP(s->b_in.reserve(total));
-    char* b = s->b_in.p;
-    SC_HIP(hipMemcpyAsync(b + o_cls, cls, n * 4, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_pos, pos, n * 4, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_end, end, n * 4, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_flag, flag, n * 2, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_mq, mapq, n, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_tf, tagflags, n, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_cb, cb24, n * 24, hipMemcpyHostToDevice, st));
-    SC_HIP(hipMemcpyAsync(b + o_ub, ub24, n * 24, hipMemcpyHostToDevice, st));
-    return sc_ingest(ctx, s, n, (const int32_t*)(b + o_cls), (const int32_t*)(b + o_pos), (const int32_t*)(b + o_end),
+    // ---- 1. the caller's arrays -> a pinned slot (worker threads).  The slot is free once its previous copy to HBM is done
+    const int ps = (int)(s->n_submits % 3), ds = (int)(s->n_submits % 2);
+    if (!s->pin_done[ps]) SC_HIP(hipEventCreateWithFlags(&s->pin_done[ps], hipEventDisableTiming));
+    else SC_HIP(hipEventSynchronize(s->pin_done[ps]));
+    if (total > s->pin_cap[ps]) {
+        // (pinning costs ~0.1 s per GB: slots are sized for batches of 4 M records once a caller sends large ones, and the
+        // whole ring -- three pinned slots, two staging buffers in HBM -- is set up by the first batch that needs it, not
+        // one piece per batch over the first three)
+        const size_t want = n > 65536 ? std::max(total, (size_t)64 * (4u << 20) + 8 * 256) : total;
+        SC_HIP(hipStreamSynchronize(ctx->s_copy));
+        SC_HIP(hipStreamSynchronize(ctx->s_compute));
+        for (int i = 0; i < 3; ++i) {
+            if (s->pin_cap[i] >= want) continue;
+            if (s->pin[i]) (void)hipHostFree(s->pin[i]);
+            s->pin[i] = nullptr;
+            s->pin_cap[i] = 0;
+            void* p = nullptr;
+            SC_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+            s->pin[i] = static_cast<char*>(p);
+            s->pin_cap[i] = want;
+            // touch every page now: the first copy into a fresh slot otherwise runs at a third of the speed (10-14 ms
+            // instead of 4 ms per 256 MB measured), and the first batches of a run are then what the GPU waits for
+            const CopyJob zero = {s->pin[i], nullptr, want};
+            parallel_fill(zero, want > (8u << 20) ? 16 : 1);
+        }
+        SC_HIP(s->b_in.reserve(want));
+        SC_HIP(s->b_in2.reserve(want));
+    }
+    char* h = s->pin[ps];
+    lap("slot ready");
+    {
+        const CopyJob jobs[8] = {{h + o_cls, cls, n * 4}, {h + o_pos, pos, n * 4}, {h + o_end, end, n * 4}, {h + o_flag, flag, n * 2},
+                                 {h + o_mq, mapq, n}, {h + o_tf, tagflags, n}, {h + o_cb, cb24, n * 24}, {h + o_ub, ub24, n * 24}};
+#ifdef TEC_SC_TRACE
+        const auto tc0 = std::chrono::steady_clock::now();
+#endif
+        parallel_copy(jobs, 8, total > (8u << 20) ? 16 : 1);
+#ifdef TEC_SC_TRACE
+        fprintf(stderr, "[sc_submit] %zu MB copied into the pinned slot in %.2f ms\n", total >> 20,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+#endif
+    }
+    // ---- 2. pinned slot -> staging buffer `ds` in HBM on the copy stream, once the ingest that last read that buffer is done
+    dvec<char>& din = ds ? s->b_in2 : s->b_in;
+    if (!s->in_free[ds]) {
+        SC_HIP(hipEventCreateWithFlags(&s->in_free[ds], hipEventDisableTiming));
+        SC_HIP(hipEventCreateWithFlags(&s->in_copied[ds], hipEventDisableTiming));
+    } else {
+        SC_HIP(hipStreamWaitEvent(ctx->s_copy, s->in_free[ds], 0));
+    }
+    char* b = din.p;
+    SC_HIP(hipMemcpyAsync(b, h, total, hipMemcpyHostToDevice, ctx->s_copy));
+    SC_HIP(hipEventRecord(s->pin_done[ps], ctx->s_copy));
+    SC_HIP(hipEventRecord(s->in_copied[ds], ctx->s_copy));
+    // ---- 3. the ingest kernels on the compute stream behind that copy
+    SC_HIP(hipStreamWaitEvent(ctx->s_compute, s->in_copied[ds], 0));
+    ++s->n_submits;
+    lap("copy queued");
+    const int rc_ingest = sc_ingest(ctx, s, n, (const int32_t*)(b + o_cls), (const int32_t*)(b + o_pos), (const int32_t*)(b + o_end),
                      (const uint16_t*)(b + o_flag), (const uint8_t*)(b + o_mq), (const uint8_t*)(b + o_cb),
-                     (const uint8_t*)(b + o_ub), (const uint8_t*)(b + o_tf));
+                     (const uint8_t*)(b + o_ub), (const uint8_t*)(b + o_tf), s->in_free[ds]);
+    lap("ingest queued");
+    return rc_ingest;
 }
 
 extern "C" int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_cls, const int32_t* d_pos, const int32_t* d_end,
@@ -875,7 +1034,7 @@ extern "C" int tec_sc_submit_device(tec_ctx* ctx, uint64_t n, const int32_t* d_c
         return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit_device: NULL array");
     if (n >= 0x7FFFFFFFull) return tec_fail(ctx, TEC_EINVAL, "tec_sc_submit_device: batch too large");
     SC_HIP(hipSetDevice(ctx->device));
-    return sc_ingest(ctx, s, n, d_cls, d_pos, d_end, d_flag, d_mapq, d_cb24, d_ub24, d_tagflags);
+    return sc_ingest(ctx, s, n, d_cls, d_pos, d_end, d_flag, d_mapq, d_cb24, d_ub24, d_tagflags, nullptr);
 }
 
 int tec_sc_expect_records(tec_ctx* ctx, uint64_t n_records) {
@@ -1042,7 +1201,7 @@ int sc_check_open(tec_ctx* ctx, const char* who, bool need_sorted) {
     if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "%s: call tec_sc_begin first", who);
     if (ctx->sc->part1_done) return tec_fail(ctx, TEC_ESTATE, "%s: part 1 is already finished", who);
     if (need_sorted && !ctx->sc->sorted) return tec_fail(ctx, TEC_ESTATE, "%s: call tec_sc_part1_sort first", who);
-    return TEC_OK;
+    return sc_settle(ctx, ctx->sc);  // (batches may still be in flight: the survivor count is the device's until then)
 }
 
 }  // namespace
@@ -1051,6 +1210,9 @@ int sc_check_open(tec_ctx* ctx, const char* who, bool need_sorted) {
 // barcode id, so every (CB,UB) key and every cell row is then local to one GPU)
 extern "C" int tec_sc_survivors(tec_ctx* ctx, uint64_t* n) {
     if (!ctx || !ctx->sc || !n) return tec_fail(ctx, TEC_ESTATE, "tec_sc_survivors: call tec_sc_begin first");
+    SC_HIP(hipSetDevice(ctx->device));
+    int rc = sc_settle(ctx, ctx->sc);
+    if (rc) return rc;
     *n = ctx->sc->n_live;
     return TEC_OK;
 }
