@@ -526,13 +526,13 @@ def single_cell(ann, eng, records):
     arrays, wl, tables = synth.make_sc_arrays(ann, records, n_cells=10000, seed=2004)
     gen_s = time.time() - t0
     n = len(arrays['pos'])
-    bench_sc.run(eng, {k: v[:1 << 23] for k, v in arrays.items()}, wl, tables, 10000, False, 10_000_000)  # warm-up: two batches of the run's size (the context keeps its staging ring and survivor arrays)
+    first = bench_sc.run(eng, arrays, wl, tables, 10000, False, 10_000_000)[2]  # first run on this context: allocates the staging ring, survivor arrays and sorted views that the context then keeps
     out, st, t, _ = bench_sc.run(eng, arrays, wl, tables, 10000, False, 10_000_000)
     gpu_ms = eng.sc_gpu_ms
     alg = 32.0 * n  # 15 B + cb 8 + ub 8 + ub_len 1 per record
     return {'metric': 'Mreads/s single-cell (--sc --se), host SoA batches -> COO counts', 'records': n,
             'value': round(n / t['total'] / 1e6, 2), 'unit': 'Mreads/s',
-            'seconds': {k: round(v, 3) for k, v in t.items()}, 'gen_s': round(gen_s, 1), 'stats': st,
+            'seconds': {k: round(v, 3) for k, v in t.items()}, 'first_run_seconds': {k: round(v, 3) for k, v in first.items()}, 'gen_s': round(gen_s, 1), 'stats': st,
             'cells_with_hits': int(len(out['cells'])), 'coo_nnz': int(len(out['coo_cell'])), 'oracle_check': res,
             'roofline': {'bound': 'hbm', 'achieved': round(alg / (gpu_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(alg / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), 'traffic': None,

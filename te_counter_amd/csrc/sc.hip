@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -102,10 +103,31 @@ struct ScBuffers {
     dvec<uint32_t> k32a, k32b;
     dvec<int32_t> s_klass, s_left, s_rite;
     dvec<uint8_t> ghead, ihead, counted;
+    // temporaries of parts 2 and 3, and their result: the sorted (cell << 32 | name) keys with their counts stay in HBM
+    // until tec_sc_fetch takes them
+    struct {
+        dvec<uint32_t> sel, selprefix, lines, lkeys, lkeys2, lines2, firstkept, qflag, qscan, qrec, nemit, emoff, cellhits, present, pred;
+        dvec<uint8_t> kept_rec;
+        dvec<uint64_t> keys, keys2, ukeys;
+        dvec<unsigned long long> scal;
+    } p23;
+    // the whitelist the tables in `wl` / `wl_table` were built from: a run with the same barcodes (the usual case: one
+    // 10x whitelist for every sample) skips packing, checking, hashing and uploading 0.7 M barcodes
+    std::shared_ptr<std::vector<uint8_t>> wl_src;
+    uint32_t wl_src_mask = 0;
+    char* pin_out = nullptr;  // pinned landing area of tec_sc_fetch when the submit ring is absent or too small
+    size_t pin_out_cap = 0;
     // GPU stream time of the phases (events around each entry point's work; includes the short host gaps
     // between its kernels, so it is an upper bound of the summed kernel time)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void free_all() {
+        p23.sel.release(); p23.selprefix.release(); p23.lines.release(); p23.lkeys.release(); p23.lkeys2.release(); p23.lines2.release();
+        p23.firstkept.release(); p23.qflag.release(); p23.qscan.release(); p23.qrec.release(); p23.nemit.release(); p23.emoff.release();
+        p23.cellhits.release(); p23.kept_rec.release(); p23.keys.release(); p23.keys2.release(); p23.ukeys.release(); p23.scal.release();
+        p23.present.release(); p23.pred.release();
+        if (pin_out) (void)hipHostFree(pin_out);
+        pin_out = nullptr;
+        pin_out_cap = 0;
         wl.release(); wl_table.release(); cls_chrom.release(); cls_skip.release();
         bcid.release(); u0.release(); u1.release(); u2.release(); rec.release();
         klass.release(); left.release(); rite.release(); stat.release();
@@ -150,8 +172,9 @@ struct tec_sc_state : ScBuffers {
     std::vector<uint32_t> cells_seen;
     std::vector<uint64_t> cells_count, cells_first;
     // results
-    std::vector<uint32_t> out_cell, coo_cell, coo_name;
-    std::vector<uint64_t> out_hits, coo_count;
+    std::vector<uint32_t> out_cell;
+    std::vector<uint64_t> out_hits;
+    uint64_t n_coo = 0;  // (cell, name, count) triplets waiting in p23.ukeys / p23.nemit
     uint64_t kept_lines = 0, n_queries = 0, n_assigned = 0;
     unsigned long long h_stat[ST_N] = {0};
     double gpu_ms = 0.0;
@@ -159,7 +182,33 @@ struct tec_sc_state : ScBuffers {
 
 namespace {
 
+#ifdef TEC_SC_TRACE
+#define SC_TRACE_BEGIN const double t_a__ = sc_trace_now()
+#define SC_TRACE_END(what)                                                                                             \
+    do {                                                                                                               \
+        const double t_b__ = sc_trace_now();                                                                           \
+        if (t_b__ - t_a__ > 0.2) fprintf(stderr, "[sc %9.2f] %6.2f ms  line %d  %.60s\n", t_b__, t_b__ - t_a__, __LINE__, what); \
+    } while (0)
+#else
+#define SC_TRACE_BEGIN
+#define SC_TRACE_END(what)
+#endif
+#ifdef TEC_SC_TRACE
+// trace build (make EXTRA=-DTEC_SC_TRACE): every HIP call that takes more than 0.2 ms, with the wall clock since the first one
+inline double sc_trace_now() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+#define SC_HIP(call)                                                                                    \
+    do {                                                                                                \
+        const double t_a = sc_trace_now();                                                              \
+        TEC_HIP(ctx, call);                                                                             \
+        const double t_b = sc_trace_now();                                                              \
+        if (t_b - t_a > 0.2) fprintf(stderr, "[sc %9.2f] %6.2f ms  line %d  %.60s\n", t_b, t_b - t_a, __LINE__, #call); \
+    } while (0)
+#else
 #define SC_HIP(call) TEC_HIP(ctx, call)
+#endif
 
 __device__ __forceinline__ uint64_t load_be64(const uint8_t* p) {
     uint64_t v;
@@ -761,34 +810,43 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
     s->bundle_keys = bundle_keys;
     s->n_wl = n_whitelist;
     s->n_class = n_class;
-    std::vector<uint64_t> packed(3 * (size_t)n_whitelist);
-    for (size_t i = 0; i < n_whitelist; ++i)
-        for (int w = 0; w < 3; ++w) {
-            uint64_t v = 0;
-            for (int b = 0; b < 8; ++b) v = (v << 8) | whitelist24[24 * i + 8 * w + b];
-            packed[3 * i + w] = v;
+    const bool same_wl = s->wl_src && s->wl_src->size() == 24 * (size_t)n_whitelist && s->wl.p && s->wl_table.p &&
+                         memcmp(s->wl_src->data(), whitelist24, 24 * (size_t)n_whitelist) == 0;
+    if (same_wl) {
+        s->wl_mask = s->wl_src_mask;
+    } else {
+        s->wl_src.reset();
+        std::vector<uint64_t> packed(3 * (size_t)n_whitelist);
+        for (size_t i = 0; i < n_whitelist; ++i)
+            for (int w = 0; w < 3; ++w) {
+                uint64_t v = 0;
+                for (int b = 0; b < 8; ++b) v = (v << 8) | whitelist24[24 * i + 8 * w + b];
+                packed[3 * i + w] = v;
+            }
+        for (size_t i = 1; i < n_whitelist; ++i) {
+            const uint64_t* a = &packed[3 * (i - 1)];
+            const uint64_t* b = &packed[3 * i];
+            if (!(a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[2] < b[2])))))
+                return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: whitelist must be strictly ascending (entry %zu)", i);
         }
-    for (size_t i = 1; i < n_whitelist; ++i) {
-        const uint64_t* a = &packed[3 * (i - 1)];
-        const uint64_t* b = &packed[3 * i];
-        if (!(a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[2] < b[2])))))
-            return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: whitelist must be strictly ascending (entry %zu)", i);
-    }
-    SC_HIP(s->wl.reserve(packed.size()));
-    SC_HIP(hipMemcpy(s->wl.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
-    {
-        uint64_t cap = 16;
-        while (cap < 2ull * n_whitelist) cap <<= 1;
-        std::vector<uint32_t> table(cap, 0u);
-        const uint32_t mask = (uint32_t)(cap - 1);
-        for (uint32_t i = 0; i < n_whitelist; ++i) {
-            uint32_t slot = (uint32_t)wl_hash(packed[3 * (size_t)i], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2]) & mask;
-            while (table[slot]) slot = (slot + 1) & mask;
-            table[slot] = i + 1;
+        SC_HIP(s->wl.reserve(packed.size()));
+        SC_HIP(hipMemcpy(s->wl.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
+        {
+            uint64_t cap = 16;
+            while (cap < 2ull * n_whitelist) cap <<= 1;
+            std::vector<uint32_t> table(cap, 0u);
+            const uint32_t mask = (uint32_t)(cap - 1);
+            for (uint32_t i = 0; i < n_whitelist; ++i) {
+                uint32_t slot = (uint32_t)wl_hash(packed[3 * (size_t)i], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2]) & mask;
+                while (table[slot]) slot = (slot + 1) & mask;
+                table[slot] = i + 1;
+            }
+            SC_HIP(s->wl_table.reserve(cap));
+            SC_HIP(hipMemcpy(s->wl_table.p, table.data(), cap * 4, hipMemcpyHostToDevice));
+            s->wl_mask = mask;
         }
-        SC_HIP(s->wl_table.reserve(cap));
-        SC_HIP(hipMemcpy(s->wl_table.p, table.data(), cap * 4, hipMemcpyHostToDevice));
-        s->wl_mask = mask;
+        s->wl_src = std::make_shared<std::vector<uint8_t>>(whitelist24, whitelist24 + 24 * (size_t)n_whitelist);
+        s->wl_src_mask = s->wl_mask;
     }
     SC_HIP(s->cls_chrom.reserve(std::max<uint32_t>(n_class, 1)));
     SC_HIP(s->cls_skip.reserve(std::max<uint32_t>(n_class, 1)));
@@ -1527,7 +1585,8 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
     tec_sc_state* s = ctx->sc;
     SC_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->s_compute;
-    s->out_cell.clear(); s->out_hits.clear(); s->coo_cell.clear(); s->coo_name.clear(); s->coo_count.clear();
+    s->out_cell.clear(); s->out_hits.clear();
+    s->n_coo = 0;
     s->kept_lines = s->n_queries = s->n_assigned = 0;
     if (kept_lines) *kept_lines = 0;
     if (n_cells_hit) *n_cells_hit = 0;
@@ -1540,19 +1599,20 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
             return tec_fail(ctx, TEC_EINVAL, "tec_sc_part23: selected barcodes must be ascending whitelist ids");
     const unsigned g = grid_for(N);
     // ---- selection mask and its exclusive prefix (number of selected ids below c)
-    dvec<uint32_t> sel, selprefix, lines, lkeys, lkeys2, lines2, firstkept, qflag, qscan, qrec, nemit, emoff, cellhits, present, pred;
-    dvec<uint8_t> kept_rec;
-    dvec<uint64_t> keys, keys2, ukeys;
-    dvec<unsigned long long> scal;
-    auto cleanup = [&]() {
-        sel.release(); selprefix.release(); lines.release(); lkeys.release(); lkeys2.release(); lines2.release();
-        firstkept.release(); qflag.release(); qscan.release(); qrec.release(); nemit.release(); emoff.release();
-        cellhits.release(); kept_rec.release(); keys.release(); keys2.release(); ukeys.release(); scal.release();
-        present.release(); pred.release();
-    };
+    // (the temporaries belong to the context: a run of the same size allocates nothing)
+    auto& B = s->p23;
+    dvec<uint32_t>&sel = B.sel, &selprefix = B.selprefix, &lines = B.lines, &lkeys = B.lkeys, &lkeys2 = B.lkeys2, &lines2 = B.lines2,
+                  &firstkept = B.firstkept, &qflag = B.qflag, &qscan = B.qscan, &qrec = B.qrec, &nemit = B.nemit, &emoff = B.emoff,
+                  &cellhits = B.cellhits, &present = B.present, &pred = B.pred;
+    dvec<uint8_t>& kept_rec = B.kept_rec;
+    dvec<uint64_t>&keys = B.keys, &keys2 = B.keys2, &ukeys = B.ukeys;
+    dvec<unsigned long long>& scal = B.scal;
+    auto cleanup = [&]() {};
 #define SC_TRY(call)                         \
     do {                                     \
+        SC_TRACE_BEGIN;                      \
         hipError_t e2__ = (call);            \
+        SC_TRACE_END(#call);                 \
         if (e2__ != hipSuccess) {            \
             cleanup();                       \
             return tec_fail(ctx, TEC_EHIP, "%s failed: %s", #call, hipGetErrorString(e2__)); \
@@ -1687,21 +1747,9 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
         SC_TRY(rocprim::run_length_encode(s->tmp.p, bytes, keys2.p, (unsigned)n_keys, ukeys.p, nemit.p, scal.p + 2, st));
         SC_TRY(hipMemcpyAsync(h_scal, scal.p, sizeof h_scal, hipMemcpyDeviceToHost, st));
         SC_TRY(hipStreamSynchronize(st));
-        const size_t nu = (size_t)h_scal[2];
-        std::vector<uint64_t> hk(nu);
-        std::vector<uint32_t> hn(nu);
-        SC_TRY(hipMemcpy(hk.data(), ukeys.p, nu * 8, hipMemcpyDeviceToHost));
-        SC_TRY(hipMemcpy(hn.data(), nemit.p, nu * 4, hipMemcpyDeviceToHost));
-        s->coo_cell.resize(nu);
-        s->coo_name.resize(nu);
-        s->coo_count.resize(nu);
-        for (size_t i = 0; i < nu; ++i) {
-            s->coo_cell[i] = (uint32_t)(hk[i] >> 32);
-            s->coo_name[i] = (uint32_t)(hk[i] & 0xFFFFFFFFull);
-            s->coo_count[i] = hn[i];
-        }
+        s->n_coo = (uint64_t)h_scal[2];  // the triplets stay in ukeys / nemit until tec_sc_fetch
     }
-    if (n_coo) *n_coo = s->coo_cell.size();
+    if (n_coo) *n_coo = s->n_coo;
     cleanup();
     return TEC_OK;
 #undef SC_TRY
@@ -1716,10 +1764,44 @@ extern "C" int tec_sc_fetch(tec_ctx* ctx, uint32_t* cell_bcid, uint64_t* cell_hi
         if (cell_bcid) memcpy(cell_bcid, s->out_cell.data(), s->out_cell.size() * 4);
         if (cell_hits) memcpy(cell_hits, s->out_hits.data(), s->out_hits.size() * 8);
     }
-    if (!s->coo_cell.empty()) {
-        if (coo_cell) memcpy(coo_cell, s->coo_cell.data(), s->coo_cell.size() * 4);
-        if (coo_name) memcpy(coo_name, s->coo_name.data(), s->coo_name.size() * 4);
-        if (coo_count) memcpy(coo_count, s->coo_count.data(), s->coo_count.size() * 8);
+    const size_t nu = (size_t)s->n_coo;
+    if (nu && (coo_cell || coo_name || coo_count)) {
+        // keys and counts -> pinned memory at PCIe speed, then worker threads split them into the caller's three arrays
+        SC_HIP(hipSetDevice(ctx->device));
+        const size_t need = nu * 12;
+        char* stage = s->pin_cap[0] >= need ? s->pin[0] : nullptr;  // (the submit ring is idle by now)
+        if (!stage) {
+            if (s->pin_out_cap < need) {
+                if (s->pin_out) (void)hipHostFree(s->pin_out);
+                s->pin_out = nullptr;
+                s->pin_out_cap = 0;
+                void* p = nullptr;
+                SC_HIP(hipHostMalloc(&p, need + need / 4, hipHostMallocDefault));
+                s->pin_out = static_cast<char*>(p);
+                s->pin_out_cap = need + need / 4;
+            }
+            stage = s->pin_out;
+        }
+        hipStream_t st = ctx->s_compute;
+        SC_HIP(hipMemcpyAsync(stage, s->p23.ukeys.p, nu * 8, hipMemcpyDeviceToHost, st));
+        SC_HIP(hipMemcpyAsync(stage + nu * 8, s->p23.nemit.p, nu * 4, hipMemcpyDeviceToHost, st));
+        SC_HIP(hipStreamSynchronize(st));
+        const uint64_t* hk = reinterpret_cast<const uint64_t*>(stage);
+        const uint32_t* hn = reinterpret_cast<const uint32_t*>(stage + nu * 8);
+        const int threads = nu > (1u << 18) ? 16 : 1;
+        const size_t per = (nu + (size_t)threads - 1) / (size_t)threads;
+        auto work = [=](int t) {
+            const size_t a = per * (size_t)t, b = std::min(nu, a + per);
+            for (size_t i = a; i < b; ++i) {
+                if (coo_cell) coo_cell[i] = (uint32_t)(hk[i] >> 32);
+                if (coo_name) coo_name[i] = (uint32_t)(hk[i] & 0xFFFFFFFFull);
+                if (coo_count) coo_count[i] = hn[i];
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& t : pool) t.join();
     }
     return TEC_OK;
 }

@@ -312,8 +312,8 @@ class Engine:
             raise KeyError('strand')
         self._check(rc)
         out = {'kept_lines': kept.value, 'cells': np.zeros(nc.value, np.uint32), 'cell_hits': np.zeros(nc.value, np.uint64),
-               'coo_cell': np.zeros(nz.value, np.uint32), 'coo_name': np.zeros(nz.value, np.uint32),
-               'coo_count': np.zeros(nz.value, np.uint64)}
+               'coo_cell': np.empty(nz.value, np.uint32), 'coo_name': np.empty(nz.value, np.uint32),
+               'coo_count': np.empty(nz.value, np.uint64)}  # (tec_sc_fetch fills every element)
         self._check(self._lib.tec_sc_fetch(self._ctx, _ptr(out['cells']), _ptr(out['cell_hits']), _ptr(out['coo_cell']),
                                            _ptr(out['coo_name']), _ptr(out['coo_count'])))
         return out
