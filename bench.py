@@ -345,6 +345,30 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def sc_source_sha():
+    """Fingerprint of the single-cell kernels' source."""
+    import hashlib
+    with open(os.path.join(ROOT, 'te_counter_amd', 'csrc', 'sc.hip'), 'rb') as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
+def sc_traffic(n_records):
+    """-> (HBM bytes of one whole single-cell job, source) from profiles/traffic.json (tools/prof_sc.sh + tools/traffic_sc.py);
+    null if not profiled at this size or on another version of sc.hip."""
+    try:
+        e = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('sc/config4/%d' % n_records)
+    except (OSError, ValueError):
+        e = None
+    if not e:
+        return None, None
+    src = {'profile_tag': e.get('tag'), 'kernel_symbol': e.get('kernel_symbol'), 'kernel_source_sha': e.get('kernel_source_sha'),
+           'collected': 'rocprofv3 --pmc, separate passes, summed over every kernel of one job; FETCH_SIZE*1024 + 64*TCC_EA0_RDREQ_128B + WRITE_SIZE*1024'}
+    if e.get('kernel_source_sha') != sc_source_sha():
+        src['stale'] = 'profiled on another version of sc.hip: not reported'
+        return None, src
+    return float(e['hbm_bytes_per_job']), src
+
+
 def traffic_for(explicit, genome, layout, order, n_units):
     """-> (HBM bytes per launch of the count kernel, where the figure comes from).  The bytes are read from the
     committed rocprofv3 --pmc passes (profiles/traffic.json, written by tools/traffic.py from separate FETCH_SIZE /
@@ -530,12 +554,13 @@ def single_cell(ann, eng, records):
     out, st, t, _ = bench_sc.run(eng, arrays, wl, tables, 10000, False, 10_000_000)
     gpu_ms = eng.sc_gpu_ms
     alg = 32.0 * n  # 15 B + cb 8 + ub 8 + ub_len 1 per record
+    traffic, traffic_src = sc_traffic(records)
     return {'metric': 'Mreads/s single-cell (--sc --se), host SoA batches -> COO counts', 'records': n,
             'value': round(n / t['total'] / 1e6, 2), 'unit': 'Mreads/s',
             'seconds': {k: round(v, 3) for k, v in t.items()}, 'first_run_seconds': {k: round(v, 3) for k, v in first.items()}, 'gen_s': round(gen_s, 1), 'stats': st,
             'cells_with_hits': int(len(out['cells'])), 'coo_nnz': int(len(out['coo_cell'])), 'oracle_check': res,
             'roofline': {'bound': 'hbm', 'achieved': round(alg / (gpu_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(alg / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'frac': round(alg / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'all tec_sc_* kernels (filter, scatter, radix sorts, epochs, drop rule, query, RLE)',
                          'gpu_stream_ms': round(gpu_ms, 2), 'algorithmic_bytes': alg}}
 

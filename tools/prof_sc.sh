@@ -1,11 +1,22 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the single-cell benchmark: bash tools/prof_sc.sh <tag> [bench_sc args]
-TAG=${1:-r01_sc}; shift
+# Kernel trace and HBM-traffic passes of the single-cell pipeline on host batches, BASELINE config 4
+# (run on the GPU box through gpurun):  bash tools/prof_sc.sh <tag> [bench_sc args]
+# One rocprofv3 run per counter group; tools/traffic_sc.py condenses gpurun_out/prof_<tag>/ into profiles/.
+set -o pipefail
+TAG=${1:-r03_sc}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+echo "--check 0 $*" > $OUT/bench_args.txt
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o out -- python3 $REPO/tools/bench_sc.py --check 0 "$@" > $OUT/trace.log 2>&1 || { echo FAILED; tail -5 $OUT/trace.log; exit 1; }
-tail -1 $OUT/trace.log | cut -c1-600
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $REPO/gpurun_out/${TAG}_kernel_stats.csv
-head -40 $REPO/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-160
+run() { # name, flags...
+  local name=$1; shift
+  echo "[prof] $name: $*"
+  timeout -s KILL 300 rocprofv3 "$@" --output-format csv -d $OUT/$name -o out -- python3 $REPO/tools/bench_sc.py --check 0 $BENCH_ARGS > $OUT/$name.log 2>&1 || { echo "[prof] $name FAILED"; tail -3 $OUT/$name.log; return 1; }
+}
+BENCH_ARGS="$*"
+run trace --kernel-trace --stats || exit 1
+run pmc_fetch --pmc FETCH_SIZE
+run pmc_write --pmc WRITE_SIZE
+run pmc_rdreq --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum
+echo "[prof] done"
