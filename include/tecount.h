@@ -251,6 +251,21 @@ int tec_sc_survivors_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* u0, uint64_t*
 int tec_sc_survivors_replace(tec_ctx* ctx, uint64_t n, const uint32_t* bcid, const uint64_t* u0, const uint64_t* u1,
                              const uint64_t* u2, const uint64_t* rec, const int32_t* klass, const int32_t* left,
                              const int32_t* rite);
+/* The same exchange without host memory (extension: the reference is one process, te_count.py:298-707; these stand where
+ * a multi-process port of its part 1 would shuffle its `umis` dict by barcode).  tec_sc_deal groups this GPU's survivors
+ * by destination GPU = barcode id % world (file order kept inside a group) into the "deal" columns and reports the
+ * group sizes; the caller moves group d to GPU d -- RCCL point-to-point on tensors wrapped over tec_sc_deal_column /
+ * tec_sc_adopt_column pointers, or tec_sc_adopt_copy between contexts of one process -- into the landing columns that
+ * tec_sc_adopt_begin(n_rows) sized; tec_sc_adopt_commit orders what arrived by record ordinal and makes it this GPU's
+ * survivors.  Columns 0..7 = bcid u0 u1 u2 rec klass left rite, element sizes 4 8 8 8 8 4 4 4 bytes.
+ * tec_sc_host_row_bytes: bytes of survivor columns that tec_sc_survivors_fetch copied to the host in this run. */
+int tec_sc_deal(tec_ctx* ctx, uint32_t world, uint64_t* counts);
+int tec_sc_deal_column(tec_ctx* ctx, int column, void** d_ptr, uint32_t* elem_bytes);
+int tec_sc_adopt_begin(tec_ctx* ctx, uint64_t n_rows);
+int tec_sc_adopt_column(tec_ctx* ctx, int column, void** d_ptr, uint32_t* elem_bytes);
+int tec_sc_adopt_copy(tec_ctx* ctx, int column, uint64_t dst_row, const void* d_src, uint64_t n_rows);
+int tec_sc_adopt_commit(tec_ctx* ctx);
+int tec_sc_host_row_bytes(tec_ctx* ctx, uint64_t* bytes);
 int tec_sc_part1_sort(tec_ctx* ctx, uint64_t* n_keys);
 int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t* first_no_ub);
 /* Ordinal of the first surviving record whose UMI does not fit the 24-byte field (~0: none); after tec_sc_part1_sort.

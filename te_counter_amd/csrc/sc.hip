@@ -115,6 +115,34 @@ struct ScBuffers {
     // 10x whitelist for every sample) skips packing, checking, hashing and uploading 0.7 M barcodes
     std::shared_ptr<std::vector<uint8_t>> wl_src;
     uint32_t wl_src_mask = 0;
+    // multi-GPU exchange on the device: the survivors grouped by destination GPU (deal) and the rows that arrive (land)
+    struct Rows {
+        dvec<uint32_t> bcid;
+        dvec<uint64_t> u0, u1, u2, rec;
+        dvec<int32_t> klass, left, rite;
+        void release() { bcid.release(); u0.release(); u1.release(); u2.release(); rec.release(); klass.release(); left.release(); rite.release(); }
+        hipError_t reserve(size_t n) {
+            hipError_t e;
+            if ((e = bcid.reserve(n)) || (e = u0.reserve(n)) || (e = u1.reserve(n)) || (e = u2.reserve(n)) || (e = rec.reserve(n)) ||
+                (e = klass.reserve(n)) || (e = left.reserve(n)) || (e = rite.reserve(n)))
+                return e;
+            return hipSuccess;
+        }
+        void* column(int c, uint32_t* elem) {
+            switch (c) {
+                case 0: *elem = 4; return bcid.p;
+                case 1: *elem = 8; return u0.p;
+                case 2: *elem = 8; return u1.p;
+                case 3: *elem = 8; return u2.p;
+                case 4: *elem = 8; return rec.p;
+                case 5: *elem = 4; return klass.p;
+                case 6: *elem = 4; return left.p;
+                case 7: *elem = 4; return rite.p;
+            }
+            *elem = 0;
+            return nullptr;
+        }
+    } deal, land;
     char* pin_out = nullptr;  // pinned landing area of tec_sc_fetch when the submit ring is absent or too small
     size_t pin_out_cap = 0;
     // GPU stream time of the phases (events around each entry point's work; includes the short host gaps
@@ -125,6 +153,8 @@ struct ScBuffers {
         p23.firstkept.release(); p23.qflag.release(); p23.qscan.release(); p23.qrec.release(); p23.nemit.release(); p23.emoff.release();
         p23.cellhits.release(); p23.kept_rec.release(); p23.keys.release(); p23.keys2.release(); p23.ukeys.release(); p23.scal.release();
         p23.present.release(); p23.pred.release();
+        deal.release();
+        land.release();
         if (pin_out) (void)hipHostFree(pin_out);
         pin_out = nullptr;
         pin_out_cap = 0;
@@ -175,6 +205,8 @@ struct tec_sc_state : ScBuffers {
     std::vector<uint32_t> out_cell;
     std::vector<uint64_t> out_hits;
     uint64_t n_coo = 0;  // (cell, name, count) triplets waiting in p23.ukeys / p23.nemit
+    uint64_t n_land = 0;         // rows the landing columns were sized for (tec_sc_adopt_begin)
+    uint64_t host_row_bytes = 0; // bytes of survivor columns that went to host memory in this run (tec_sc_survivors_fetch)
     uint64_t kept_lines = 0, n_queries = 0, n_assigned = 0;
     unsigned long long h_stat[ST_N] = {0};
     double gpu_ms = 0.0;
@@ -362,6 +394,47 @@ __global__ void sc_scatter_kernel(uint64_t n, uint64_t rec_base, const unsigned 
 // Behind the scatter of a batch: the output cursor moves on by the batch's survivors.
 __global__ void sc_advance_kernel(uint64_t n, const uint32_t* __restrict__ live, const uint32_t* __restrict__ scan, unsigned long long* cursor) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *cursor += (unsigned long long)scan[n - 1] + live[n - 1];
+}
+
+// destination GPU of every survivor (cells are dealt by barcode id) and how many go where
+__global__ void deal_key_kernel(uint64_t n, const uint32_t* __restrict__ bcid, uint32_t world, uint32_t* key, unsigned long long* counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned int tally[64];
+    if (threadIdx.x < 64) tally[threadIdx.x] = 0;
+    __syncthreads();
+    if (i < n) {
+        const uint32_t d = bcid[i] % world;
+        key[i] = d;
+        atomicAdd(&tally[d & 63u], 1u);  // (world <= 64)
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && threadIdx.x < world && tally[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
+// which UMI bits are set anywhere, and the largest record ordinal, of rows that arrived from other GPUs
+__global__ void land_summary_kernel(uint64_t n, const uint64_t* __restrict__ u0, const uint64_t* __restrict__ u1,
+                                    const uint64_t* __restrict__ u2, const uint64_t* __restrict__ rec, unsigned long long* out4) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long a = 0, b = 0, c = 0, m = 0;
+    if (i < n) {
+        a = u0[i];
+        b = u1[i];
+        c = u2[i];
+        m = rec[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a |= __shfl_down(a, off, 64);
+        b |= __shfl_down(b, off, 64);
+        c |= __shfl_down(c, off, 64);
+        const unsigned long long o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicOr(&out4[0], a);
+        if (b) atomicOr(&out4[1], b);
+        if (c) atomicOr(&out4[2], c);
+        atomicMax(&out4[3], m);
+    }
 }
 
 template <class T>
@@ -1285,6 +1358,7 @@ extern "C" int tec_sc_survivors_fetch(tec_ctx* ctx, uint32_t* bcid, uint64_t* u0
     if (!bcid || !u0 || !u1 || !u2 || !rec || !klass || !left || !rite) return tec_fail(ctx, TEC_EINVAL, "tec_sc_survivors_fetch: NULL array");
     SC_HIP(hipSetDevice(ctx->device));
     SC_HIP(hipStreamSynchronize(ctx->s_compute));
+    s->host_row_bytes += n * 52;
     SC_HIP(hipMemcpy(bcid, s->bcid.p, n * 4, hipMemcpyDeviceToHost));
     SC_HIP(hipMemcpy(u0, s->u0.p, n * 8, hipMemcpyDeviceToHost));
     SC_HIP(hipMemcpy(u1, s->u1.p, n * 8, hipMemcpyDeviceToHost));
@@ -1344,6 +1418,137 @@ extern "C" int tec_sc_survivors_replace(tec_ctx* ctx, uint64_t n, const uint32_t
     if ((rc = col64(u0, s->u0.p)) || (rc = col64(u1, s->u1.p)) || (rc = col64(u2, s->u2.p))) return rc;
     if ((rc = col32(bcid, s->bcid.p)) || (rc = col32(klass, s->klass.p)) || (rc = col32(left, s->left.p)) || (rc = col32(rite, s->rite.p))) return rc;
     SC_HIP(hipStreamSynchronize(st));
+    return TEC_OK;
+}
+
+// ---- the same exchange without the host: the survivors are grouped by destination on the device (tec_sc_deal), the
+// caller moves the groups between GPUs (RCCL point-to-point on tensors wrapped over the deal / landing columns, or
+// tec_sc_adopt_copy between contexts of one process), tec_sc_adopt_commit orders what arrived by record ordinal.
+// Columns are numbered as tec_sc_survivors_fetch lists them: bcid u0 u1 u2 rec klass left rite.
+extern "C" int tec_sc_deal(tec_ctx* ctx, uint32_t world, uint64_t* counts) {
+    int rc = sc_check_open(ctx, "tec_sc_deal", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (s->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_deal: after tec_sc_part1_sort");
+    if (!counts || world == 0 || world > 64) return tec_fail(ctx, TEC_EINVAL, "tec_sc_deal: 1 <= world <= 64");
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    for (uint32_t d = 0; d < world; ++d) counts[d] = 0;
+    const uint64_t n = s->n_live;
+    if (!n) return TEC_OK;
+    const unsigned g = grid_for(n);
+    SC_HIP(s->deal.reserve(n));
+    SC_HIP(s->perm.reserve(n)); SC_HIP(s->perm2.reserve(n)); SC_HIP(s->k32a.reserve(n)); SC_HIP(s->k32b.reserve(n));
+    SC_HIP(s->marks.reserve(64));
+    SC_HIP(hipMemsetAsync(s->marks.p, 0, 64 * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(deal_key_kernel, dim3(g), dim3(kB), 0, st, n, s->bcid.p, world, s->k32a.p, reinterpret_cast<unsigned long long*>(s->marks.p));
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, n, s->perm.p);
+    // stable: inside a destination's group the rows keep their file order
+    rc = sort_pairs(ctx, s, s->k32a.p, s->k32b.p, s->perm.p, s->perm2.p, n, 0, bits_for(world));
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->bcid.p, s->deal.bcid.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->u0.p, s->deal.u0.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->u1.p, s->deal.u1.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->u2.p, s->deal.u2.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->rec.p, s->deal.rec.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->klass.p, s->deal.klass.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->left.p, s->deal.left.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->rite.p, s->deal.rite.p);
+    SC_HIP(hipGetLastError());
+    unsigned long long h[64];
+    SC_HIP(hipMemcpyAsync(h, s->marks.p, world * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));  // (the caller's transport reads the deal columns from other streams)
+    for (uint32_t d = 0; d < world; ++d) counts[d] = h[d];
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_deal_column(tec_ctx* ctx, int column, void** d_ptr, uint32_t* elem_bytes) {
+    if (!ctx || !ctx->sc || !d_ptr || !elem_bytes) return tec_fail(ctx, TEC_ESTATE, "tec_sc_deal_column: no single-cell run");
+    *d_ptr = ctx->sc->deal.column(column, elem_bytes);
+    if (!*elem_bytes) return tec_fail(ctx, TEC_EINVAL, "tec_sc_deal_column: columns are 0..7");
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_adopt_begin(tec_ctx* ctx, uint64_t n_rows) {
+    int rc = sc_check_open(ctx, "tec_sc_adopt_begin", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (s->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_adopt_begin: after tec_sc_part1_sort");
+    if (n_rows >= 0xFFFFFFF0ull) return tec_fail(ctx, TEC_EOVERFLOW, "tec_sc_adopt_begin: more than 2^32 rows");
+    SC_HIP(hipSetDevice(ctx->device));
+    SC_HIP(s->land.reserve(std::max<uint64_t>(n_rows, 1)));
+    s->n_land = n_rows;
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_adopt_column(tec_ctx* ctx, int column, void** d_ptr, uint32_t* elem_bytes) {
+    if (!ctx || !ctx->sc || !d_ptr || !elem_bytes) return tec_fail(ctx, TEC_ESTATE, "tec_sc_adopt_column: no single-cell run");
+    *d_ptr = ctx->sc->land.column(column, elem_bytes);
+    if (!*elem_bytes) return tec_fail(ctx, TEC_EINVAL, "tec_sc_adopt_column: columns are 0..7");
+    return TEC_OK;
+}
+
+// n_rows of a column from device memory of this process (a peer context's deal column, or this context's own) into the
+// landing column from row dst_row on.
+extern "C" int tec_sc_adopt_copy(tec_ctx* ctx, int column, uint64_t dst_row, const void* d_src, uint64_t n_rows) {
+    if (!ctx || !ctx->sc) return tec_fail(ctx, TEC_ESTATE, "tec_sc_adopt_copy: no single-cell run");
+    tec_sc_state* s = ctx->sc;
+    uint32_t elem = 0;
+    char* dst = static_cast<char*>(s->land.column(column, &elem));
+    if (!elem) return tec_fail(ctx, TEC_EINVAL, "tec_sc_adopt_copy: columns are 0..7");
+    if (dst_row + n_rows > s->n_land) return tec_fail(ctx, TEC_EINVAL, "tec_sc_adopt_copy: beyond the rows announced to tec_sc_adopt_begin");
+    if (!n_rows) return TEC_OK;
+    if (!d_src) return tec_fail(ctx, TEC_EINVAL, "tec_sc_adopt_copy: NULL source");
+    SC_HIP(hipSetDevice(ctx->device));
+    SC_HIP(hipMemcpyAsync(dst + dst_row * elem, d_src, n_rows * elem, hipMemcpyDeviceToDevice, ctx->s_compute));
+    SC_HIP(hipStreamSynchronize(ctx->s_compute));  // (the source may be another context's buffer: done before that context moves on)
+    return TEC_OK;
+}
+
+extern "C" int tec_sc_adopt_commit(tec_ctx* ctx) {
+    int rc = sc_check_open(ctx, "tec_sc_adopt_commit", false);
+    if (rc) return rc;
+    tec_sc_state* s = ctx->sc;
+    if (s->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_adopt_commit: after tec_sc_part1_sort");
+    SC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s_compute;
+    const uint64_t n = s->n_land;
+    SC_HIP(s->marks.reserve(64));
+    SC_HIP(hipMemsetAsync(s->marks.p, 0, 4 * sizeof(uint64_t), st));
+    if (n) hipLaunchKernelGGL(land_summary_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->land.u0.p, s->land.u1.p, s->land.u2.p, s->land.rec.p,
+                              reinterpret_cast<unsigned long long*>(s->marks.p));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    SC_HIP(hipMemcpyAsync(h, s->marks.p, sizeof h, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    if (n && h[3] + 1 > s->max_rec) s->max_rec = h[3] + 1;
+    SC_HIP(hipMemcpy(s->stat.p + ST_OR0, h, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    s->n_live = n;
+    if (!n) return TEC_OK;
+    SC_HIP(s->bcid.reserve(n)); SC_HIP(s->u0.reserve(n)); SC_HIP(s->u1.reserve(n)); SC_HIP(s->u2.reserve(n));
+    SC_HIP(s->rec.reserve(n)); SC_HIP(s->klass.reserve(n)); SC_HIP(s->left.reserve(n)); SC_HIP(s->rite.reserve(n));
+    SC_HIP(s->perm.reserve(n)); SC_HIP(s->perm2.reserve(n));
+    const unsigned g = grid_for(n);
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, n, s->perm.p);
+    // file order = ascending record ordinal (the groups arrive per source GPU, each in its own file order)
+    rc = sort_pairs(ctx, s, s->land.rec.p, s->rec.p, s->perm.p, s->perm2.p, n, 0, bits_for(h[3] + 1));
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.bcid.p, s->bcid.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.u0.p, s->u0.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.u1.p, s->u1.p);
+    hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.u2.p, s->u2.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.klass.p, s->klass.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.left.p, s->left.p);
+    hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, n, s->perm2.p, s->land.rite.p, s->rite.p);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(st));
+    return TEC_OK;
+}
+
+// Bytes of survivor columns that tec_sc_survivors_fetch has copied to host memory in this run (0 when the exchange ran
+// on the device).
+extern "C" int tec_sc_host_row_bytes(tec_ctx* ctx, uint64_t* bytes) {
+    if (!ctx || !ctx->sc || !bytes) return tec_fail(ctx, TEC_ESTATE, "tec_sc_host_row_bytes: no single-cell run");
+    *bytes = ctx->sc->host_row_bytes;
     return TEC_OK;
 }
 

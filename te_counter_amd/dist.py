@@ -214,6 +214,71 @@ def all_gather_array(world, a):
     return [_as_array(o, a.dtype)[:n].copy() for o, n in zip(outs, sizes)]
 
 
+_COLUMN_TORCH = {4: 'int32', 8: 'int64'}  # (bit patterns travel; signedness does not matter)
+
+
+def _wrap_device(address, n, elem_bytes, device_index):
+    """A torch tensor over n elements of library-owned HBM (no copy)."""
+    import torch
+
+    class _Wrap:
+        __cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<i%d' % elem_bytes, 'data': (int(address), False), 'version': 2}
+    return torch.as_tensor(_Wrap(), device=torch.device('cuda', device_index))
+
+
+def exchange_survivors(world, eng):
+    """The survivors of a single-cell run change GPUs without visiting host memory: eng.sc_deal groups them by
+    destination in HBM, every pair of GPUs exchanges its group once (RCCL point-to-point on tensors wrapped over the
+    library's deal / landing columns), eng.sc_adopt_commit orders what arrived by record ordinal.
+    With the gloo backend -- ranks that share one GPU, or CPU-only rehearsals -- the groups are staged through host
+    tensors, because gloo moves host memory only.  A test world may bring its own transport (`exchange_device`)."""
+    counts = eng.sc_deal(world.size)
+    sizes = world.gather(counts)  # sizes[src][dst]
+    n_in = sum(sizes[src][world.rank] for src in range(world.size))
+    eng.sc_adopt_begin(n_in)
+    out_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    in_off = np.concatenate([[0], np.cumsum([sizes[src][world.rank] for src in range(world.size)])]).astype(np.int64)
+    if hasattr(world, 'exchange_device'):
+        world.exchange_device(eng, sizes, out_off, in_off)
+    else:
+        import torch
+        import torch.distributed as dist
+        on_host = world.backend != 'nccl'
+        for col in range(8):
+            src_addr, elem = eng.sc_deal_column(col)
+            dst_addr, _ = eng.sc_adopt_column(col)
+            send = _wrap_device(src_addr, out_off[-1], elem, eng.device) if out_off[-1] else None
+            recv = _wrap_device(dst_addr, n_in, elem, eng.device) if n_in else None
+            ops, keep, landed = [], [], []
+            for peer in range(world.size):
+                n_out, n_peer = sizes[world.rank][peer], sizes[peer][world.rank]
+                if peer == world.rank:
+                    if n_out:
+                        eng.sc_adopt_copy(col, in_off[peer], src_addr + int(out_off[peer]) * elem, n_out)
+                    continue
+                if n_out:
+                    t = send[out_off[peer]:out_off[peer] + n_out]
+                    if on_host:
+                        t = t.cpu()  # (synchronous copy: gloo takes host tensors only)
+                    keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, peer))
+                if n_peer:
+                    r = recv[in_off[peer]:in_off[peer] + n_peer]
+                    if on_host:
+                        h = torch.empty(n_peer, dtype=r.dtype)
+                        landed.append((r, h))
+                        r = h
+                    ops.append(dist.P2POp(dist.irecv, r, peer))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for r, h in landed:
+                r.copy_(h)
+            if not on_host:
+                torch.cuda.synchronize()
+    eng.sc_adopt_commit()
+
+
 def exchange_rows(world, parts):
     """All-to-all of row sets: parts[d] = {column: array} destined for rank d (same columns and dtypes on
     every rank).  Returns the columns received from all ranks, concatenated in source-rank order.

@@ -252,6 +252,39 @@ class Engine:
         cols = [np.ascontiguousarray(rows[k], dt) for k, dt in self._SURVIVOR_COLUMNS]
         self._check(self._lib.tec_sc_survivors_replace(self._ctx, len(cols[0]), *[_ptr(c) for c in cols]))
 
+    # ---- the exchange on the device (include/tecount.h, tec_sc_deal ...): what dist.exchange_survivors drives
+    def sc_deal(self, world_size):
+        """Groups the survivors by destination GPU (barcode id % world) in HBM -> rows per destination."""
+        counts = np.zeros(int(world_size), np.uint64)
+        self._check(self._lib.tec_sc_deal(self._ctx, int(world_size), _ptr(counts)))
+        return [int(c) for c in counts]
+
+    def _sc_column(self, fn, column):
+        p, e = C.c_void_p(), C.c_uint32()
+        self._check(fn(self._ctx, int(column), C.byref(p), C.byref(e)))
+        return int(p.value or 0), int(e.value)
+
+    def sc_deal_column(self, column):
+        """-> (device address, element bytes) of deal column 0..7 (bcid u0 u1 u2 rec klass left rite)."""
+        return self._sc_column(self._lib.tec_sc_deal_column, column)
+
+    def sc_adopt_begin(self, n_rows):
+        self._check(self._lib.tec_sc_adopt_begin(self._ctx, int(n_rows)))
+
+    def sc_adopt_column(self, column):
+        return self._sc_column(self._lib.tec_sc_adopt_column, column)
+
+    def sc_adopt_copy(self, column, dst_row, src_address, n_rows):
+        self._check(self._lib.tec_sc_adopt_copy(self._ctx, int(column), int(dst_row), C.c_void_p(int(src_address)), int(n_rows)))
+
+    def sc_adopt_commit(self):
+        self._check(self._lib.tec_sc_adopt_commit(self._ctx))
+
+    def sc_host_row_bytes(self):
+        b = C.c_uint64()
+        self._check(self._lib.tec_sc_host_row_bytes(self._ctx, C.byref(b)))
+        return int(b.value)
+
     def sc_part1_sort(self):
         n = C.c_uint64()
         self._check(self._lib.tec_sc_part1_sort(self._ctx, C.byref(n)))

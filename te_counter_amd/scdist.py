@@ -8,7 +8,7 @@ the bundle reader drops (:509-543).  Here cells are dealt to the GPUs by barcode
 every cell row is local to one GPU, and exactly those three things are agreed on globally:
 
     record ordinals   base = records in the ranks before this one            (one gather)
-    survivors         all-to-all by barcode id % world                        (RCCL point-to-point)
+    survivors         all-to-all by barcode id % world, HBM to HBM               (RCCL point-to-point)
     bundle boundaries the ordinal whose global rank among "records that open a new key since the last
                       flush" is bundle_keys, by bisection over per-GPU rank queries (all-reduce of one
                       integer per probe)
@@ -34,10 +34,13 @@ def run_parts(eng, world, n_records_local, bundle_keys, maxcells, pad):
     base, total = sum(counts[:world.rank]), sum(counts)
     eng.sc_set_record_base(base, total)
     if world.size > 1:  # deal the survivors to the GPUs by barcode id
-        rows = eng.sc_survivors()
-        dest = rows['bcid'] % np.uint32(world.size)
-        parts = [{k: v[dest == r] for k, v in rows.items()} for r in range(world.size)]
-        eng.sc_survivors_replace(_dist.exchange_rows(world, parts))
+        if hasattr(eng, 'sc_deal'):  # in HBM: grouped by a kernel, moved GPU to GPU, ordered on arrival
+            _dist.exchange_survivors(world, eng)
+        else:  # (the numpy stand-in engine of the CPU tests)
+            rows = eng.sc_survivors()
+            dest = rows['bcid'] % np.uint32(world.size)
+            parts = [{k: v[dest == r] for k, v in rows.items()} for r in range(world.size)]
+            eng.sc_survivors_replace(_dist.exchange_rows(world, parts))
     n_keys = eng.sc_part1_sort()
     # the reference dies at the first record (file order) that lacks a barcode / UMI tag (te_count.py:409, 426)
     missing = world.gather(eng.sc_missing_tags())

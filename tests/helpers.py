@@ -66,6 +66,20 @@ class ThreadWorld:
         allparts = self.gather(parts)
         return {c: np.concatenate([allparts[src][self.rank][c] for src in range(self.size)]) for c in parts[0]}
 
+    def exchange_device(self, eng, sizes, out_off, in_off):
+        """dist.exchange_survivors' transport for contexts of one process: every rank publishes the device addresses of
+        its deal columns, every rank copies its groups out of its peers' columns (device to device), and nobody moves on
+        before all copies are done."""
+        addrs = self.gather([eng.sc_deal_column(c) for c in range(8)])
+        offs = self.gather([int(x) for x in out_off])
+        for src in range(self.size):
+            n = sizes[src][self.rank]
+            for c in range(8):
+                a, elem = addrs[src][c]
+                if n:
+                    eng.sc_adopt_copy(c, int(in_off[src]), a + offs[src][self.rank] * elem, n)
+        self._s.barrier.wait()
+
     def mine(self, ordinal):
         return ordinal % self.size == self.rank
 

@@ -95,7 +95,12 @@ def test_cells_dealt_over_several_gpu_contexts(name, world, tmp_path):
             m = measureTE('t', p['q'], world=ThreadWorld(r, shared))
             m.BUNDLE_KEYS = p['bundle_threshold']
             m.bind_genome(flat)
+            m.load_genome()
+            host_bytes = []
+            end = m._engine.sc_end
+            m._engine.sc_end = lambda: (host_bytes.append(m._engine.sc_host_row_bytes()), end())[1]
             res = m.sc_parse_bamse(path, whitelistfilename=str(wlf), strand=p['strand'], label='lab', maxcells=p['maxcells'])
+            assert host_bytes == [0]  # the survivors changed contexts in HBM: no column of them went through host memory
             if r == 0:
                 o = str(tmp_path / 'o.tsv')
                 m.sc_save_result(res, o, maxcells=p['maxcells'])
