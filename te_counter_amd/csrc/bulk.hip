@@ -1259,10 +1259,15 @@ extern "C" int tec_bulk_finish(tec_ctx* ctx, uint64_t* counts, tec_stats* stats)
     if (rc) return rc;
     unsigned long long h[8];
     TEC_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
-    if (counts) {  // device vector is in internal (hotness) order
-        std::vector<uint64_t> tmp(ctx->idx.n_names);
-        TEC_HIP(ctx, hipMemcpy(tmp.data(), ctx->d_counts, tmp.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < ctx->idx.n_names; ++i) counts[ctx->int2ext[i]] = tmp[i];
+    if (counts) {  // the device vector is in internal (hotness) order: permuted on the device, into the allocation's second half
+        const uint32_t n_names = ctx->idx.n_names;
+        unsigned long long* const ordered = ctx->d_counts + n_names + 8;
+        hipLaunchKernelGGL(noalloc_export_kernel, dim3((n_names + 255u) / 256u), dim3(256), 0, ctx->s_compute,
+                           (const unsigned long long*)ctx->d_counts, (const uint32_t*)ctx->d_int2ext, n_names,
+                           (const unsigned long long*)ctx->d_stats, ordered, (unsigned long long*)nullptr);
+        TEC_HIP(ctx, hipGetLastError());
+        TEC_HIP(ctx, hipMemcpyAsync(counts, ordered, (size_t)n_names * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->s_compute));
+        TEC_HIP(ctx, hipStreamSynchronize(ctx->s_compute));
     }
     if (stats) {
         stats->units = h[0];

@@ -328,7 +328,8 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     if (e == hipSuccess) e = hipMalloc(&d_i2e, (size_t)n_names * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(d_i2e, int2ext.data(), (size_t)n_names * sizeof(uint32_t), hipMemcpyHostToDevice);
     // + 8: the carry bookkeeping of the packed LDS counters may touch the slot after the last name (bulk.hip)
-    if (e == hipSuccess) e = hipMalloc(&counts, ((size_t)n_names + 8) * sizeof(unsigned long long));
+    // (twice: the second half takes the counts in the caller's name order on their way out, see tec_bulk_finish)
+    if (e == hipSuccess) e = hipMalloc(&counts, 2 * ((size_t)n_names + 8) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(counts, 0, ((size_t)n_names + 8) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipFree(blob);
