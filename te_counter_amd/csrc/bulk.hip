@@ -964,7 +964,9 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
     // names that do not fit go to a bucketed spill list (FastSink): its bucket cursors live behind the histogram
     unsigned name_bits = 1;
     while (name_bits < 32 && (ctx->idx.n_names >> name_bits)) ++name_bits;
-    const uint32_t spill_lo = name_bits > 8 ? std::min(name_bits - 8, 14u) : 0u;
+    // (at most 128 buckets of at most 32 768 names: every bucket is a write stream of its own in the count kernel, whose
+    // partly filled lines compete for the L2, and 128 KiB is the fold's LDS histogram)
+    const uint32_t spill_lo = name_bits > 7 ? std::min(name_bits - 7, 15u) : 0u;
     const uint32_t n_buckets = (ctx->idx.n_names + (1u << spill_lo) - 1u) >> spill_lo;
     const bool may_spill = ctx->idx.n_names > budget / 2 && ctx->spill_enabled && n_buckets <= 1024 && ctx->kernel_variant == 2 &&
                            ctx->idx.n_chrom <= kChromLds && ctx->rec_ne == 3;
@@ -1004,7 +1006,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
         // room for three names per unit, spread over the buckets (a unit adds at most six on the fast path,
         // config 5 averages 1.45); a slice that fills up falls back to global atomics
         const uint64_t per_wg = (n + grid - 1) / grid;
-        spill_cap = (uint32_t)std::min<uint64_t>((per_wg * 3 + n_buckets - 1) / n_buckets + 64, 0xFFFFFFull);
+        spill_cap = (uint32_t)std::min<uint64_t>((per_wg * 3 + n_buckets - 1) / n_buckets + 64, 0xFFFFFFull) & ~3u;  // (the fold reads 16 bytes a lane)
         int rc = tec_spill_reserve(ctx, grid, n_buckets, spill_cap);
         if (rc) return rc;
     }

@@ -18,27 +18,52 @@
 
 namespace {
 
-// Workgroup b: slices (b, 0..n_wg) of `slice_cap` entries, `counts[b * n_wg + wg]` of them valid.
+// Workgroup (b, s): slices (b, wg) of `slice_cap` entries (a multiple of four: the slices are read sixteen bytes
+// a lane), `counts[b * n_wg + wg]` of them valid, for the wg that fall to part s of gridDim.y.  A slice holds a few
+// thousand names, so a wave that read it four bytes a lane and one load at a time spent the launch waiting for
+// memory: here a lane has four 16-byte loads in flight before its first LDS add.
 __global__ __launch_bounds__(1024) void spill_bucket_kernel(const uint32_t* __restrict__ spill, const uint32_t* __restrict__ counts,
                                                             uint32_t n_wg, uint32_t slice_cap, uint32_t lo, uint32_t n_names,
                                                             unsigned long long* out, unsigned long long* total) {
     extern __shared__ uint32_t hist[];
-    const uint32_t size = 1u << lo, b = blockIdx.x;
+    const uint32_t size = 1u << lo, mask = size - 1u, b = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < size; i += 1024u) hist[i] = 0;
     __syncthreads();
-    // 16 waves: each takes every 16th slice, its lanes stride over the slice
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t first = wave + 16u * blockIdx.y, step = 16u * gridDim.y;
     uint32_t seen = 0;
-    for (uint32_t wg = wave; wg < n_wg; wg += 16u) {
+    for (uint32_t wg = first; wg < n_wg; wg += step) {
         const uint32_t n = counts[(size_t)b * n_wg + wg];
-        const uint32_t* __restrict__ src = spill + ((size_t)b * n_wg + wg) * slice_cap;
-        for (uint32_t i = lane; i < n; i += 64u) atomicAdd(&hist[src[i] & (size - 1u)], 1u);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(spill + ((size_t)b * n_wg + wg) * slice_cap);
+        const uint32_t nv = (n + 3u) >> 2;
+        for (uint32_t i = lane; i < nv; i += 256u) {
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t at = i + 64u * k;
+                v[k] = at < nv ? src[at] : uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t at = (i + 64u * k) * 4u;  // (beyond n for the vectors that were not loaded)
+                if (at < n) atomicAdd(&hist[v[k].x & mask], 1u);
+                if (at + 1u < n) atomicAdd(&hist[v[k].y & mask], 1u);
+                if (at + 2u < n) atomicAdd(&hist[v[k].z & mask], 1u);
+                if (at + 3u < n) atomicAdd(&hist[v[k].w & mask], 1u);
+            }
+        }
         seen += lane == 0 ? n : 0u;
     }
     __syncthreads();
+    const bool alone = gridDim.y == 1u;  // this workgroup owns the bucket's names: plain adds
     for (uint32_t i = threadIdx.x; i < size; i += 1024u) {
-        const uint32_t name = (b << lo) + i;
-        if (hist[i] && name < n_names) out[name] += hist[i];  // this workgroup owns the bucket's names
+        const uint32_t name = (b << lo) + i, h = hist[i];
+        if (h && name < n_names) {
+            if (alone)
+                out[name] += h;
+            else
+                atomicAdd(&out[name], (unsigned long long)h);
+        }
     }
     if (seen) atomicAdd(total, (unsigned long long)seen);
 }
@@ -62,6 +87,8 @@ int tec_spill_reserve(tec_ctx* ctx, uint32_t n_wg, uint32_t n_buckets, uint32_t 
     int rc = grow(ctx, &ctx->d_spill, &ctx->spill_cap_total, (size_t)n_wg * n_buckets * slice_cap);
     if (rc) return rc;
     if (!ctx->d_spill_total) {
+        // (a bucket of 32 768 names is 128 KiB of histogram: more than 64 KiB of dynamic LDS has to be asked for)
+        TEC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&spill_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         TEC_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_spill_total), 8));
         TEC_HIP(ctx, hipMemset(ctx->d_spill_total, 0, 8));
     }
@@ -78,7 +105,9 @@ int tec_spill_fold(tec_ctx* ctx, uint32_t n_wg, uint32_t n_buckets, uint32_t lo,
         ctx->spill_ev.push_back(p);
     }
     tec_event_pair& ev = ctx->spill_ev[ctx->spill_ev_used++];
-    hipExtLaunchKernelGGL(spill_bucket_kernel, dim3(n_buckets), dim3(1024), (uint32_t)(4u << lo), ctx->s_compute, ev.start, ev.stop, 0u,
+    // fewer buckets than CUs: several workgroups share a bucket's slices (and add with atomics)
+    const uint32_t parts = std::max(1u, std::min((uint32_t)ctx->n_cu / n_buckets, 8u));
+    hipExtLaunchKernelGGL(spill_bucket_kernel, dim3(n_buckets, parts), dim3(1024), (uint32_t)(4u << lo), ctx->s_compute, ev.start, ev.stop, 0u,
                           (const uint32_t*)ctx->d_spill, (const uint32_t*)ctx->d_spill_counts, n_wg, slice_cap, lo, ctx->idx.n_names,
                           ctx->d_counts, ctx->d_spill_total);
     TEC_HIP(ctx, hipGetLastError());
