@@ -83,6 +83,27 @@ class measureTE:
         return open_alignment(filename, batch_size=self.batch_size, byte_range=byte_range)
 
     @staticmethod
+    def _as_source(filename):
+        """A path stays a path (the native decoders read BAM and SAM).  An OPEN pysam-style alignment
+        file -- what the reference itself holds after `pysam.AlignmentFile(filename, 'r')`
+        (te_count.py:65,190,351) -- and a CRAM path (read through pysam when it is installed; neither native
+        decoder reads CRAM) go through the record-by-record adapter."""
+        if hasattr(filename, 'batches'):
+            return filename
+        if isinstance(filename, (str, bytes, os.PathLike)):
+            if os.fsdecode(filename).lower().endswith('.cram'):
+                try:
+                    import pysam
+                except ImportError as e:
+                    raise ImportError('%s: CRAM input needs pysam (it is not installed); convert to BAM with '
+                                      '`samtools view -b`' % os.fsdecode(filename)) from e
+                return _reads.SegmentSource(pysam.AlignmentFile(os.fsdecode(filename), 'r'))
+            return filename
+        if hasattr(filename, 'references'):
+            return _reads.SegmentSource(filename)
+        return filename
+
+    @staticmethod
     def _decoder_for(filename):
         """'gpu': BGZF-compressed BAM files are decoded on the device (csrc/gbam.hip); 'cpu': the host
         decoder (csrc/bamio.hip) -- SAM text, in-memory sources, or TEC_DECODER=cpu."""
@@ -95,6 +116,7 @@ class measureTE:
         assert filename, 'You must specify a filename'
         if strand:
             raise NotImplementedError()  # te_count.py:58-59, 183-184
+        filename = self._as_source(filename)
         log = log or _NullLog()
         assert self.genome is not None, 'call load_genome() first'
         eng, world = self._engine, self.world
@@ -266,6 +288,7 @@ class measureTE:
         if not os.path.exists(whitelistfilename):
             raise AssertionError(f'{whitelistfilename} -w whitelist file not found')
         whitelist, packed_whitelist = _reads.load_whitelist(whitelistfilename)  # te_count.py:330-339
+        filename = self._as_source(filename)
         self.barcodes = {}
         q = self.quality_threshold
         q_int = int(q) if isinstance(q, (int, np.integer)) else None

@@ -11,6 +11,7 @@ import numpy as np
 from .index import read_chrom_key
 
 FLAG_FILTER = 0x4 | 0x200 | 0x400
+NO_END = -2 ** 31  # reference_end of a record without CIGAR (pysam gives None); the same value as bam.NO_END
 
 
 class RecordBatch:
@@ -62,6 +63,52 @@ class ListSource:
             yield RecordBatch(tid, [r['pos'] for r in chunk], [r['end'] for r in chunk],
                               [r['flag'] for r in chunk], [r['mapq'] for r in chunk],
                               qname=[r.get('qname', 'q') for r in chunk], cb=cb, ub=ub)
+
+    def close(self):
+        pass
+
+
+class SegmentSource:
+    """Adapter over an open pysam-style alignment file: any iterable of segment objects with the
+    attributes the reference reads from a `pysam.AlignedSegment` -- `flag`, `mapping_quality`,
+    `query_name`, `reference_id`, `reference_start`, `reference_end` (None without a CIGAR),
+    `get_tags()` -- plus the file's `references` tuple (te_count.py:65,78-98 / 190,203-214 /
+    351,393-438).  It is the way in for inputs the native decoders do not read (CRAM through pysam,
+    a filtered iterator, records made in memory); the records take the host path record by record,
+    so this is the slow door, not the product path.  The caller keeps ownership of the file."""
+
+    def __init__(self, segments, references=None, batch_size=1 << 20):
+        self.segments = segments
+        refs = references if references is not None else getattr(segments, 'references', None)
+        if refs is None:
+            raise TypeError('SegmentSource: the alignment file has no `references` and none were given')
+        self.reference_names = list(refs)
+        self.batch_size = batch_size
+
+    def batches(self, want_tags=False):
+        tid, pos, end, flag, mapq, qname, cb, ub = [], [], [], [], [], [], [], []
+
+        def batch():
+            return RecordBatch(tid, pos, end, flag, mapq, qname=qname, cb=cb if want_tags else None,
+                               ub=ub if want_tags else None)
+
+        for seg in self.segments:
+            tid.append(seg.reference_id)
+            pos.append(seg.reference_start)
+            e = seg.reference_end
+            end.append(NO_END if e is None else e)
+            flag.append(seg.flag)
+            mapq.append(seg.mapping_quality)
+            qname.append(seg.query_name)
+            if want_tags:
+                tags = dict(seg.get_tags())  # te_count.py:403: a later tag of the same name wins
+                cb.append(tags['CB'] if 'CB' in tags else tags.get('CR'))
+                ub.append(tags['UB'] if 'UB' in tags else tags.get('UR'))
+            if len(tid) == self.batch_size:
+                yield batch()
+                tid, pos, end, flag, mapq, qname, cb, ub = [], [], [], [], [], [], [], []
+        if tid:
+            yield batch()
 
     def close(self):
         pass

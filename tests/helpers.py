@@ -24,6 +24,35 @@ def flat_from_golden(g):
     return FlatIndex.from_features(g['features'])
 
 
+class FakeSegment:
+    """The attributes of a pysam.AlignedSegment that the reference reads (te_count.py:81-98, 204-214, 394-438)."""
+
+    def __init__(self, r, tid):
+        self.reference_id = tid
+        self.reference_name = r.get('rname')
+        self.reference_start = r['pos']
+        self.reference_end = r['end']  # (None: no CIGAR)
+        self.flag = r['flag']
+        self.mapping_quality = r['mapq']
+        self.query_name = r.get('qname', 'q')
+        self._tags = list(r.get('tags', {}).items())
+
+    def get_tags(self):
+        return list(self._tags)
+
+
+class FakeAlignmentFile:
+    """Stands in for an open pysam.AlignmentFile (pysam is not installed here): `references` and iteration."""
+
+    def __init__(self, records):
+        self.references = tuple(R.ListSource(records).reference_names)
+        tid = {n: i for i, n in enumerate(self.references)}
+        self._segments = [FakeSegment(r, tid.get(r.get('rname'), -1)) for r in records]
+
+    def __iter__(self):
+        return iter(self._segments)
+
+
 class ThreadWorld:
     """Test double of te_counter_amd.dist.World for N ranks that are THREADS of one process (e.g. N engine
     contexts on one GPU): the collectives scdist / measure use, over a shared mailbox and a barrier."""

@@ -8,7 +8,7 @@ import pytest
 
 import datagen as dg
 from te_counter_amd import bam
-from te_counter_amd.reads import ListSource, PairAssembler, sc_batch_arrays, chrom_class_table, se_units
+from te_counter_amd.reads import ListSource, PairAssembler, SegmentSource, sc_batch_arrays, chrom_class_table, se_units
 
 
 def _records(n, seed=3, sc=False):
@@ -311,3 +311,41 @@ def test_thread_count_from_the_environment(tmp_path, monkeypatch):
         cols = [got[k].tolist() for k in ('tid', 'pos', 'end', 'flag', 'mapq', 'qkey')]
         ref = ref or cols
         assert cols == ref and len(cols[0]) == len(recs)
+
+
+@pytest.mark.parametrize('sc', [False, True])
+def test_pysam_style_file_through_the_adapter(sc):
+    """An open pysam-style alignment file (te_count.py:65,190,351 hold one) gives the same batches as the record dicts."""
+    from helpers import FakeAlignmentFile
+    recs = _records(3001, seed=8, sc=sc)
+    if sc:  # (a record whose only barcode / UMI tags are the raw ones: te_count.py:405-406, 423-424)
+        recs[5]['tags'] = {'CR': recs[5]['tags']['CB'], 'UR': recs[5]['tags']['UB']}
+    a = _collect(SegmentSource(FakeAlignmentFile(recs), batch_size=700), want_tags=sc)
+    b = _collect(ListSource(recs, batch_size=700), want_tags=sc)
+    assert len(a) == len(b) == 5
+    assert SegmentSource(FakeAlignmentFile(recs)).reference_names == ListSource(recs).reference_names
+    for x, y in zip(a, b):
+        for f in ('tid', 'pos', 'end', 'flag', 'mapq'):
+            assert np.array_equal(getattr(x, f), getattr(y, f)), f
+        assert x.qname == y.qname and x.cb == y.cb and x.ub == y.ub
+    # reference_end is None without a CIGAR
+    f = FakeAlignmentFile(recs[:3])
+    f._segments[1].reference_end = None
+    (batch,) = _collect(SegmentSource(f))
+    assert batch.end[1] == bam.NO_END and batch.end[0] == recs[0]['end']
+    with pytest.raises(TypeError):
+        SegmentSource(iter(()))  # no reference names to be had
+
+
+def test_cram_path_without_pysam_says_so(tmp_path):
+    from te_counter_amd.measure import measureTE
+    p = tmp_path / 'x.CRAM'
+    p.write_bytes(b'CRAM')
+    try:
+        import pysam  # noqa: F401
+        pytest.skip('pysam is installed')
+    except ImportError:
+        pass
+    with pytest.raises(ImportError, match='CRAM input needs pysam'):
+        measureTE._as_source(str(p))
+    assert measureTE._as_source('reads.bam') == 'reads.bam'

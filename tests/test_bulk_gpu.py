@@ -38,6 +38,19 @@ def test_golden_through_measureTE(name, tmp_path):
     assert open(out).read() == g['expected']['tsv']
 
 
+@pytest.mark.parametrize('name', ['bulk_se_quirks', 'bulk_pe_quirks_odd', 'bulk_pe_rand11'])
+def test_golden_from_a_pysam_style_file(name):
+    """measureTE takes what the reference itself holds after `pysam.AlignmentFile(...)` (te_count.py:65,190)."""
+    from helpers import FakeAlignmentFile
+    g = load_golden(name)
+    m = measureTE('test', g['params']['q'])
+    m.bind_genome(flat_from_golden(g))
+    m.load_genome()
+    res = (m.parse_bampe if g['params']['paired'] else m.parse_bamse)(FakeAlignmentFile(g['records']))
+    assert m.total_reads == g['expected']['total_reads']
+    assert res == g['expected']['result']
+
+
 @pytest.mark.parametrize('name,exc', [('bulk_err_enhancer', NameError), ('bulk_err_strand', NotImplementedError),
                                       ('bulk_err_qlist', TypeError), ('bulk_err_pe_mismatch', AttributeError)])
 def test_failure_modes(name, exc):

@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 SC = [n for n in golden_names('sc_') if '_err_' not in n]
 
 
-def run_sc(flat, records, whitelist, maxcells, strand, q, bundle_keys, tmp_path, batch_size=997, umis=True):
+def run_sc(flat, records, whitelist, maxcells, strand, q, bundle_keys, tmp_path, batch_size=997, umis=True, source=None):
     wl = tmp_path / 'wl.txt'
     wl.write_text(''.join(b + '\n' for b in whitelist))
     m = measureTE('test', q)
     m.BUNDLE_KEYS = bundle_keys
     m.bind_genome(flat)
-    res = m.sc_parse_bamse(ListSource(records, batch_size=batch_size), UMIS=umis, whitelistfilename=str(wl),
+    res = m.sc_parse_bamse(source or ListSource(records, batch_size=batch_size), UMIS=umis, whitelistfilename=str(wl),
                            strand=strand, label='lab', maxcells=maxcells)
     out = str(tmp_path / 'o.tsv')
     m.sc_save_result(res, out, maxcells=maxcells)
@@ -40,6 +40,19 @@ def test_golden(name, tmp_path):
     assert res == g['expected']['result']
     assert tsv == g['expected']['tsv']
     assert freq == g['expected']['barcode_freq']
+
+
+@pytest.mark.parametrize('name', ['sc_rand21_strand', 'sc_topcells_binding_multibundle'])
+def test_golden_from_a_pysam_style_file(name, tmp_path):
+    """sc_parse_bamse over what the reference holds after `pysam.AlignmentFile(...)` (te_count.py:351)."""
+    from helpers import FakeAlignmentFile
+    g = load_golden(name)
+    p = g['params']
+    m, res, tsv, freq = run_sc(flat_from_golden(g), g['records'], g['whitelist'], p['maxcells'], p['strand'], p['q'],
+                               p['bundle_threshold'], tmp_path, source=FakeAlignmentFile(g['records']))
+    assert m.total_reads == g['expected']['total_reads']
+    assert res == g['expected']['result']
+    assert tsv == g['expected']['tsv']
 
 
 @pytest.mark.parametrize('name,exc', [('sc_err_no_strand_key', KeyError), ('sc_err_noumi', ZeroDivisionError),
