@@ -219,14 +219,15 @@ def spawn_ranks(n):
 class BulkRun:
     """An index replica on the engine's GPU and one HBM-resident batch of synthetic units."""
 
-    def __init__(self, eng, ann, layout, order, records, seed, bin_shift=0):
+    def __init__(self, eng, ann, layout, order, records, seed, bin_shift=0, stranded=False):
         import torch
         from te_counter_amd import synth
         self.eng, self.ann = eng, ann
+        self.stranded = stranded  # the stranded-bulk extension (tec_bulk_set_stranded): a strand-split index
         self.paired = layout == 'pe'
         self.rec_per_unit = 2 if self.paired else 1
         self.n_units = records // 2 if self.paired else records
-        eng.upload_index(ann.flat, bin_shift)
+        eng.upload_index(ann.flat.strand_split() if stranded else ann.flat, bin_shift)
         self.info = eng.index_info()
         self.units = synth.make_units(ann, self.n_units, seed=seed, paired=self.paired, order=order)
         self.dev = [torch.from_numpy(u.view(np.int16) if u.dtype == np.uint16 else u).cuda() for u in self.units]
@@ -273,6 +274,8 @@ class BulkRun:
 
     def count(self, steps):
         self.eng.bulk_begin(20)
+        if self.stranded:
+            self.eng.bulk_set_stranded(True)
         for _ in range(steps):
             self.eng.bulk_submit_device(self.n_units, *self.ptrs)
         return self.eng.bulk_finish()
@@ -566,15 +569,20 @@ def single_cell(ann, eng, records):
 
 
 def secondary(ann, eng, args):
-    """BASELINE configs 2 and 5 on the count kernel, each with its own roofline."""
+    """BASELINE configs 2 and 5 on the count kernel, each with its own roofline; config 3 as named (bulk PE with --strand,
+    which the reference refuses: te_count.py:58-59) through the stranded-bulk extension -- no reference output exists for
+    it, so that entry says `"pinned": false`."""
     from te_counter_amd import synth
     out = {}
     for key, a, layout, order, genome in (('config2_100M_SE_hg38_shuffled', ann, 'se', 'shuffled', 'hg38'),
                                           ('config2_100M_SE_hg38_sorted', ann, 'se', 'sorted', 'hg38'),
-                                          ('config5_100M_SE_3M_names', None, 'se', 'shuffled', 'custom3m')):
+                                          ('config5_100M_SE_3M_names', None, 'se', 'shuffled', 'custom3m'),
+                                          ('config3_125M_PE_mm10_stranded_extension', None, 'pe', 'shuffled', 'mm10')):
+        stranded = 'stranded' in key
         if a is None:
-            a = synth.make_custom_annotation()
-        run = BulkRun(eng, a, layout, order, 100_000_000, seed=2002 if genome == 'hg38' else 2005)
+            a = synth.make_annotation('mm10') if genome == 'mm10' else synth.make_custom_annotation()
+        run = BulkRun(eng, a, layout, order, 125_000_000 if stranded else 100_000_000,
+                      seed={'hg38': 2002, 'mm10': 2003}.get(genome, 2005), stranded=stranded)
         K = 20  # one job = begin, K launches over the resident batch, finish (D2H of the count vector: 24 MB for 3 M names)
         run.count(2)
         t = time.perf_counter()
@@ -586,10 +594,15 @@ def secondary(ann, eng, args):
         single, _ = run.count(1)
         if not np.array_equal(counts, single * K):
             raise SystemExit('PARITY FAILURE: linearity violated in ' + key)
-        out[key] = {'value': round(run.n_units * K / dt / 1e6, 1), 'unit': 'Mreads/s', 'steps': K, 'ms_per_step': round(dt / K * 1e3, 4),
+        out[key] = {'value': round(run.n_units * run.rec_per_unit * K / dt / 1e6, 1), 'unit': 'Mreads/s', 'steps': K,
+                    'ms_per_step': round(dt / K * 1e3, 4),
                     'names': a.flat.n_names, 'assigned_frac': round(st['assigned'] / K / run.n_units, 4),
                     'roofline': run.roofline(kernel_ms, launches, reduce_ms, launch_ms,
-                                             traffic_for(None, genome, layout, order, run.n_units))}
+                                             (None, None) if stranded else traffic_for(None, genome, layout, order, run.n_units))}
+        if stranded:
+            out[key]['pinned'] = False
+            out[key]['note'] = 'extension: the reference raises NotImplementedError for bulk --strand; checked only against the oracle run per strand (tests/test_bulk_gpu.py)'
+
         if spill_names:  # names beyond the LDS histogram: listed by the count kernel, folded by spill_bucket_kernel behind it
             out[key]['spill_fold_ms_per_launch'] = round(spill_ms / max(1, launches), 3)
             out[key]['spilled_names_per_launch'] = int(spill_names // max(1, launches))

@@ -117,7 +117,8 @@ int tec_index_info(const tec_ctx* ctx, uint64_t* n_entries, uint64_t* n_bins, in
  *     reference_name.replace('chr','') is not an index key (te_count.py:96-102, 212-218);
  *   - set p1 = reference_start, p2 = reference_end (SE, te_count.py:213-214) or
  *     p1 = read1.reference_start, p2 = read2.reference_start (PE, te_count.py:97-98);
- *   - PE: OR-ed both mates' flags into `flag` and taken read1's mapq (te_count.py:81-88).
+ *   - PE: OR-ed both mates' flags into `flag` (except TEC_FLAG_REVERSE, which is read 1's: only
+ *     tec_bulk_set_stranded looks at it) and taken read1's mapq (te_count.py:81-88).
  * The unit layout is therefore the same for SE and PE: 15 bytes per unit.
  */
 int tec_bulk_begin(tec_ctx* ctx, int mapq_min);
@@ -136,6 +137,16 @@ int tec_bulk_submit_device(tec_ctx* ctx, uint64_t n_units, const int32_t* d_chro
 
 /* Wait for everything submitted so far. */
 int tec_bulk_sync(tec_ctx* ctx);
+
+/* EXTENSION, no counterpart in the reference: bulk counting that respects the read strand.  The reference refuses
+ * `--strand` for bulk input before it reads anything (NotImplementedError, te_count.py:58-59, 183-184), so no reference
+ * output exists for it and nothing pins this mode; it applies the single-cell path's rule (te_count.py:654, 665: a
+ * feature counts only if its strand equals '-' for a reverse read, '+' otherwise) to the bulk loops.  The caller builds
+ * the index STRAND-SPLIT -- chromosome 2c holds the '+' features of chromosome c, 2c + 1 its '-' features, features of
+ * any other strand are left out -- and calls this between tec_bulk_begin and the first submit; units keep the plain
+ * chromosome id c, and TEC_FLAG_REVERSE of a unit's flag selects the copy (PE: the host puts read 1's bit there).
+ * tec_bulk_begin switches it off again. */
+int tec_bulk_set_stranded(tec_ctx* ctx, int on);
 
 /* One batch counted from start to finish WITHOUT ANY ALLOCATION.  No counterpart in the reference (which allocates
  * Python objects per read): this entry point is for callers that cannot call hipMalloc -- code under HIP graph

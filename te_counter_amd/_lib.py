@@ -52,6 +52,7 @@ _SIGNATURES = {
     'tec_bulk_wait': (C.c_int, [_p, _u64]),
     'tec_bulk_submit_device': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p]),
     'tec_bulk_sync': (C.c_int, [_p]),
+    'tec_bulk_set_stranded': (C.c_int, [_p, C.c_int]),
     'tec_bulk_count_noalloc': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, C.c_int, _p, _p, _p]),
     'tec_bulk_device_buffers': (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p)]),
     'tec_bulk_finish': (C.c_int, [_p, _p, C.POINTER(Stats)]),

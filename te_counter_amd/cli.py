@@ -23,6 +23,9 @@ _SWITCHES = [
     (('--sc',), dict(action='store_true', help='count per cell barcode (CB/CR tag) instead of per sample; needs --se and -w')),
     (('--noumi',), dict(action='store_true', help='with --sc: the library carries no UMI tag (UB/UR)')),
     (('--strand',), dict(action='store_true', help='respect read strand (stranded protocols); off unless given')),
+    (('--bulk-strand-extension',), dict(action='store_true', help='bulk input with --strand: count features of the read\'s own '
+                                        'strand only (read 1\'s for pairs) instead of refusing; an extension with no '
+                                        'reference output to compare with')),
     (('-q', '--qual'), dict(type=int, default=20, help='drop records whose MAPQ is below this value [20]')),
     (('--maxcells',), dict(type=int, default=10000, help='with --sc: number of best-covered cells written [10000]')),
     (('-w',), dict(type=str, default='', help='with --sc: text file listing the accepted cell barcodes, one per line')),
@@ -66,11 +69,12 @@ class Job:
     maxcells: int
     whitelist: str
     device: object
+    bulk_strand_extension: bool = False
 
     @classmethod
     def from_args(cls, a):
         return cls(a.inbam[0], a.outtsv[0], a.genome[0], a.mode[0], a.se, a.sc, not a.noumi, a.strand, a.qual,
-                   a.maxcells, a.w, a.device)
+                   a.maxcells, a.w, a.device, a.bulk_strand_extension)
 
     @property
     def label(self):
@@ -117,6 +121,7 @@ def _run_single_cell(mte, job, world, log):
 
 def _run_bulk(mte, job, world, log):
     mte.load_genome()
+    mte.bulk_strand_extension = job.bulk_strand_extension
     counter = mte.parse_bamse if job.single_end else mte.parse_bampe
     table = counter(job.inbam, strand=job.strand, log=log)
     if world.rank == 0:

@@ -269,6 +269,9 @@ __device__ __forceinline__ void store_hist(const uint32_t* hist, uint32_t words4
 // the next sync): slot s holds used.n[s] rows of `stride` words at slabs + s * slot_rows * stride.
 // blockIdx.y strides over the rows so that enough loads are in flight.
 constexpr int kSlabSlots = 8;
+// kernel flag: the index holds every chromosome twice, 2c = its '+' features and 2c + 1 = its '-' features, and a unit
+// looks at the copy of its own strand (tec_bulk_set_stranded)
+constexpr uint32_t kStrandedRun = 64u;
 struct SlabRows {
     uint32_t n[kSlabSlots];
 };
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
                     (flags & 16u) ? 32u : ((flags & 32u) ? 0xFFFFFFFFu : 0u)};
     unsigned sinkhole = 0;  // keeps ablated loads alive
     const tec_entry* __restrict__ ent = idx.entries;
+    const uint32_t sbit = (flags & kStrandedRun) ? 1u : 0u;  // see tec_bulk_set_stranded
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
     // A workgroup owns spans of consecutive chunks, `gridDim.x` spans apart: at any moment the
     // workgroups are spread over the batch (for coordinate-sorted input: over the genome, so
@@ -361,10 +365,11 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
             } else if ((int)mq[k] < mapq_min) {
                 ++n_lowq;
                 live[k] = false;
-            } else if (ch[k] < 0 || (uint32_t)ch[k] >= idx.n_chrom) {
+            } else if (ch[k] < 0 || (uint32_t)ch[k] >= (idx.n_chrom >> sbit)) {
                 ++n_bad;
                 live[k] = false;
             } else {
+                ch[k] = (int)(((uint32_t)ch[k] << sbit) + (sbit & (fl[k] >> 4)));  // stranded index: chromosome 2c + reverse
                 const uint32_t nb = idx.chrom_nbins[ch[k]], cb = idx.chrom_base[ch[k]];
                 const uint32_t ba = (uint32_t)un[k].p1 >> idx.shift, bb = (uint32_t)un[k].p2 >> idx.shift;
                 if (un[k].p1 >= 0 && ba < nb) {
@@ -590,6 +595,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     unsigned sinkhole = 0;                // keeps ablated loads alive
 #endif
     const tec_entry* __restrict__ ent = idx.entries;
+    const uint32_t sbit = (flags & kStrandedRun) ? 1u : 0u;  // see tec_bulk_set_stranded
     unsigned n_assigned = 0, n_enh = 0;        // per lane (incremented in divergent code)
     unsigned w_lowq = 0, w_bad = 0, w_qc = 0;  // per wave (scalar)
     TEC_CLK_DECL;
@@ -662,7 +668,9 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
         for (int k = 0; k < U; ++k) {
             const bool qc = live[k] && (fl[k] & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) != 0;
             const bool lowq = live[k] && !qc && (int)mq[k] < mapq_min;
-            const bool chrom_ok = (uint32_t)ch[k] < idx.n_chrom;  // negative ids wrap to huge values
+            const bool chrom_ok = (uint32_t)ch[k] < (idx.n_chrom >> sbit);  // negative ids wrap to huge values
+            // (stranded index: chromosome 2c + the unit's reverse bit; the exact walk below looks ch up again)
+            ch[k] = chrom_ok ? (int)(((uint32_t)ch[k] << sbit) + (sbit & (fl[k] >> 4))) : ch[k];
             const bool bad = live[k] && !qc && !lowq && !chrom_ok;
             // wave-uniform tallies on the scalar unit (one s_bcnt1 each), lane 0 carries them out
             w_qc += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(qc));
@@ -1014,7 +1022,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
                           dim3(kBlock), (uint32_t)lds, ctx->s_compute, timed ? ev.start : (hipEvent_t) nullptr,
                           timed ? ev.stop : (hipEvent_t) nullptr, 0u, ctx->idx, u.chrom, u.p1, u.p2,
                           u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                          (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate, slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
+                          (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate | (ctx->stranded ? kStrandedRun : 0u), slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
                           spill_cap | (spill_lo << 24), ctx->d_spill_counts);
     TEC_HIP(ctx, hipGetLastError());
     if (spilling) {
@@ -1101,6 +1109,7 @@ extern "C" int tec_bulk_begin(tec_ctx* ctx, int mapq_min) {
     int rc = harvest_timers(ctx);
     if (rc) return rc;
     ctx->mapq_min = mapq_min;
+    ctx->stranded = false;
     ctx->slab_slot = 0;
     ctx->kernel_ms = 0.0;
     ctx->reduce_ms = 0.0;
@@ -1230,6 +1239,17 @@ extern "C" int tec_bulk_count_noalloc(tec_ctx* ctx, uint64_t n, const int32_t* d
                        (const uint32_t*)ctx->d_int2ext, n_names, (const unsigned long long*)stats,
                        reinterpret_cast<unsigned long long*>(d_counts_out), reinterpret_cast<unsigned long long*>(d_stats_out));
     TEC_HIP(ctx, hipGetLastError());
+    return TEC_OK;
+}
+
+extern "C" int tec_bulk_set_stranded(tec_ctx* ctx, int on) {
+    if (!ctx) return tec_fail(ctx, TEC_EINVAL, "tec_bulk_set_stranded: NULL context");
+    if (!ctx->bulk_open) return tec_fail(ctx, TEC_ESTATE, "tec_bulk_set_stranded: no bulk run is open");
+    if (ctx->kernel_launches) return tec_fail(ctx, TEC_ESTATE, "tec_bulk_set_stranded: units were already submitted to this run");
+    if (on && (ctx->idx.n_chrom & 1u))
+        return tec_fail(ctx, TEC_EINVAL, "tec_bulk_set_stranded: the index has %u chromosomes: a strand-split index has two per chromosome",
+                        ctx->idx.n_chrom);
+    ctx->stranded = on != 0;
     return TEC_OK;
 }
 

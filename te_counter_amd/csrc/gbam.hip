@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256) void pair_kernel(uint64_t n_units, uint64_t fi
     const uint64_t u = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (u >= n_units) return;
     const uint64_t a = first + 2u * u, b = a + 1u;
-    const uint32_t fl = (uint32_t)r.flag[a] | (uint32_t)r.flag[b];
+    // (the flags OR-ed for the filters; the reverse bit is read 1's alone: only the stranded-bulk extension looks at it)
+    const uint32_t fa = r.flag[a];
+    const uint32_t fl = ((fa | (uint32_t)r.flag[b]) & ~(uint32_t)TEC_FLAG_REVERSE) | (fa & (uint32_t)TEC_FLAG_REVERSE);
     const uint32_t mq = r.mapq[a];
     u_chrom[u] = r.chrom[a];
     u_p1[u] = r.pos[a];

@@ -93,6 +93,7 @@ struct tec_ctx {
     int n_cu = 256;
     int unroll = 2;  // units carried per lane by the count kernel
     int aggregate = 0;
+    bool stranded = false;  // this bulk run counts against a strand-split index (tec_bulk_set_stranded)
     int kernel_variant = 2;
     bool force_mixed = false;
     int rec_ne_wanted = 3;  // inline entries per bin record asked for (TEC_REC_NE)

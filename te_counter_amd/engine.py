@@ -98,6 +98,10 @@ class Engine:
         self._ring_ticket = [0, 0, 0]  # (tec_bulk_begin drains both streams)
         self._check(self._lib.tec_bulk_begin(self._ctx, int(mapq_min)))
 
+    def bulk_set_stranded(self, on=True):
+        """tec_bulk_set_stranded: this run counts against a strand-split index (FlatIndex.strand_split)."""
+        self._check(self._lib.tec_bulk_set_stranded(self._ctx, int(bool(on))))
+
     def bulk_submit(self, chrom, p1, p2, flag, mapq, stage=True):
         """Host SoA batch (numpy).  stage=True: the batch is copied into one of three page-locked slots
         (tec_alloc_pinned) first, so that the call returns while the copy to HBM is still running and the

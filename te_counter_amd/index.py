@@ -138,6 +138,20 @@ class FlatIndex:
             feats.append(f)
         return cls.from_features(feats)
 
+    def strand_split(self):
+        """The index of the stranded-bulk EXTENSION (tec_bulk_set_stranded; the reference refuses bulk `--strand`,
+        te_count.py:58-59): chromosome 2c holds the '+' features of chromosome c, 2c + 1 its '-' features; features
+        of any other (or no) strand can match no read strand (te_count.py:654: '-' if read.is_reverse else '+')
+        and are left out.  Names and name ids are unchanged; reads keep the plain chromosome id c (`tid_map` of
+        the unsplit index)."""
+        sid = (self.meta >> _lib.META_STRAND_SHIFT) & 7
+        plus = self.strands.index('+') if '+' in self.strands else -1
+        minus = self.strands.index('-') if '-' in self.strands else -1
+        keep = (sid == plus) | (sid == minus)
+        keys = [k + s for k in self.chrom_keys for s in ('\x00+', '\x00-')]  # (never equal to a read's chromosome key)
+        chrom = 2 * self.chrom_id[keep] + (sid[keep] == minus)
+        return FlatIndex(self.names, keys, self.strands, chrom, self.left[keep], self.right[keep], self.meta[keep], True)
+
     # ------------------------------------------------------------------ queries the host needs
     def chrom_id_of_read(self, reference_name):
         """-1 unless reference_name.replace('chr','') is an index key (te_count.py:96-102)."""

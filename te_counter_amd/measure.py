@@ -38,6 +38,11 @@ class measureTE:
         self.genome = None
         self.stats = {}
         self._engine = None
+        # EXTENSION, off unless set: parse_bamse / parse_bampe(strand=True) count with the single-cell path's strand
+        # rule (te_count.py:654, 665) instead of raising what the reference raises (te_count.py:58-59, 183-184).
+        # No reference output exists for it: nothing pins its results.
+        self.bulk_strand_extension = False
+        self._split_for = None  # the FlatIndex whose strand-split form is resident on the GPU instead of itself
         if world is None:
             from .dist import World
             world = World()
@@ -74,6 +79,18 @@ class measureTE:
             self._engine = Engine(self.device)
         self._engine.upload_index(self.genome, self.bin_shift)
         self._resident = key
+        self._split_for = None
+
+    def _index_for(self, stranded):
+        """The plain index, or (stranded-bulk extension) its strand-split form, resident on the GPU."""
+        if stranded:
+            if self._split_for is not self.genome:
+                self._engine.upload_index(self.genome.strand_split(), self.bin_shift)
+                self._split_for = self.genome
+                self._resident = None
+        elif self._split_for is not None:
+            self._resident = None
+            self.load_genome()
 
     # ------------------------------------------------------------------ bulk
     def _open(self, filename, byte_range=None):
@@ -114,17 +131,20 @@ class measureTE:
 
     def _bulk(self, filename, paired, strand, log):
         assert filename, 'You must specify a filename'
-        if strand:
+        if strand and not self.bulk_strand_extension:
             raise NotImplementedError()  # te_count.py:58-59, 183-184
         filename = self._as_source(filename)
         log = log or _NullLog()
         assert self.genome is not None, 'call load_genome() first'
+        self._index_for(bool(strand))
         eng, world = self._engine, self.world
         q = self.quality_threshold
         q_int = int(q) if isinstance(q, (int, np.integer)) else None
         n_records, failure, stats, counts = 0, None, None, None
         try:
             eng.bulk_begin(q_int or 0)
+            if strand:
+                eng.bulk_set_stranded(True)
             if self._decoder_for(filename) == 'gpu':
                 n_records, failure = self._bulk_gpu_decode(filename, paired, q_int or 0)
             else:

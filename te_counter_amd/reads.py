@@ -162,7 +162,8 @@ class PairAssembler:
             self._carry = (tid[-1], pos[-1], flag[-1], mapq[-1], qn[-1] if qn is not None else None)
             n -= 1
         t1, p1, p2 = tid[0:n:2], pos[0:n:2], pos[1:n:2]
-        fl = (flag[0:n:2] | flag[1:n:2]).astype(np.uint16)
+        # (the reverse bit is read 1's alone: nothing but the stranded-bulk extension looks at it)
+        fl = (((flag[0:n:2] | flag[1:n:2]) & ~np.uint16(0x10)) | (flag[0:n:2] & np.uint16(0x10))).astype(np.uint16)
         mq = mapq[0:n:2]
         if qn is not None:
             self._check_names(qn, n, fl, mq)

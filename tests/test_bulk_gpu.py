@@ -147,3 +147,84 @@ def test_empty_and_tiny(engine):
     got, st = engine.bulk_finish()
     want, _ = c_oracle.COracleIndex.from_flat(flat).bulk_count(*[u[:1] for u in units], 20)
     assert np.array_equal(got, want)
+
+
+def _one_strand(flat, strand):
+    sid = (flat.meta >> 29) & 7
+    keep = sid == flat.strands.index(strand)
+    return FlatIndex(flat.names, flat.chrom_keys, flat.strands, flat.chrom_id[keep], flat.left[keep], flat.right[keep], flat.meta[keep])
+
+
+def _stranded_oracle(flat, units, q):
+    """The extension's definition, restated with the pinned oracle: forward units against the '+' features only,
+    reverse units against the '-' features only (te_count.py:654, 665 is the rule; bulk `--strand` itself has no
+    reference output, te_count.py:58-59)."""
+    rev = (units[3] & 0x10) != 0
+    total, stats = None, None
+    for strand, pick in (('+', ~rev), ('-', rev)):
+        c, st = c_oracle.COracleIndex.from_flat(_one_strand(flat, strand)).bulk_count(*[u[pick] for u in units], q)
+        total = c if total is None else total + c
+        stats = st if stats is None else {k: stats[k] + st[k] for k in st}
+    return total, stats
+
+
+@pytest.mark.parametrize('countable_only', [True, False])
+@pytest.mark.parametrize('csr_kernel', [False, True])
+def test_stranded_extension_counts_per_strand(countable_only, csr_kernel, monkeypatch):
+    flat, units = _dense_case(91, 60000, 400000, 2000000, countable_only)
+    want, wst = _stranded_oracle(flat, units, 20)
+    plain, _ = c_oracle.COracleIndex.from_flat(flat).bulk_count(*units, 20)
+    assert 0 < int(want.sum()) < int(plain.sum())
+    if csr_kernel:
+        monkeypatch.setenv('TEC_KERNEL', '1')
+    eng = Engine(0)
+    try:
+        split = flat.strand_split()
+        assert len(split.chrom_keys) == 2 * len(flat.chrom_keys) and split.names == flat.names
+        eng.upload_index(split)
+        eng.bulk_begin(20)
+        eng.bulk_set_stranded(True)
+        for a in range(0, len(units[0]), 99991):
+            eng.bulk_submit(*[u[a:a + 99991] for u in units])
+        got, gst = eng.bulk_finish()
+        assert np.array_equal(got, want)
+        assert {k: gst[k] for k in wst} == wst
+        # the switch does not outlive its run, and an index with an odd number of chromosomes is refused
+        eng.upload_index(flat)
+        eng.bulk_begin(20)
+        with pytest.raises(Exception, match='two per chromosome'):
+            eng.bulk_set_stranded(True)
+        eng.bulk_submit(*units)
+        got, _ = eng.bulk_finish()
+        assert np.array_equal(got, plain)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize('paired', [False, True])
+def test_stranded_extension_through_measureTE(paired, tmp_path):
+    """strand=True stays the reference's NotImplementedError unless the extension is switched on; with it, records ->
+    units (PE: read 1's strand) -> per-strand counts, the same from a BAM file (GPU decoder) and from records in memory;
+    an unstranded call afterwards sees the plain index again."""
+    from te_counter_amd import bam
+    feats = dg.make_features(41, 4000, span=600000)
+    recs = dg.make_records(42, 30001, feats, span=600000, paired=paired)
+    flat = FlatIndex.from_features(feats)
+    units, _ = units_from_records(flat, recs, paired)
+    want, _ = _stranded_oracle(flat, units, 20)
+    plain, _ = c_oracle.COracleIndex.from_flat(flat).bulk_count(*units, 20)
+    assert 0 < int(want.sum()) < int(plain.sum())
+    m = measureTE('test', 20)
+    m.bind_genome(flat)
+    m.load_genome()
+    call = m.parse_bampe if paired else m.parse_bamse
+    with pytest.raises(NotImplementedError):
+        call(ListSource(recs), strand=True)
+    m.bulk_strand_extension = True
+    path = str(tmp_path / 'x.bam')
+    bam.write_bam(path, ListSource(recs).reference_names, recs)
+    for src in (ListSource(recs, batch_size=4001), path):
+        res = call(src, strand=True)
+        assert [res[n] for n in flat.names] == want.tolist()
+    res = call(path)
+    assert [res[n] for n in flat.names] == plain.tolist()

@@ -227,3 +227,19 @@ def test_no_torch_switch():
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=ROOT,
                            env=dict(os.environ, TEC_NO_TORCH=value))
         assert r.returncode == 0 and r.stdout.strip() == want, (value, r.stdout, r.stderr[-500:])
+
+
+def test_strand_split_index():
+    """FlatIndex.strand_split: chromosome 2c = the '+' features of c, 2c + 1 = its '-' features, others dropped."""
+    from te_counter_amd import FlatIndex
+    feats = [dict(chr='chr1', left=10, right=20, name='a', type='protein_coding', ensg='A', strand='+'),
+             dict(chr='chr1', left=30, right=40, name='b', type='LINE', ensg='B', strand='-'),
+             dict(chr='chr2', left=5, right=9, name='c', type='LINE', ensg='C', strand='.'),
+             dict(chr='chr2', left=50, right=90, name='d', type='LINE', ensg='D', strand='-')]
+    flat = FlatIndex.from_features(feats)
+    sp = flat.strand_split()
+    assert sp.names == flat.names == ['A', 'B', 'C', 'D']
+    assert len(sp.chrom_keys) == 4 and len(set(sp.chrom_keys)) == 4
+    assert sp.chrom_id.tolist() == [0, 1, 3] and sp.left.tolist() == [10, 30, 50]
+    assert (sp.meta & ((1 << 26) - 1)).tolist() == [0, 1, 3]
+    assert all(flat._chrom_lookup.get(k) is None for k in sp.chrom_keys)
