@@ -42,7 +42,8 @@ TESTS_SH = [
 @pytest.mark.parametrize('line,want', TESTS_SH, ids=[str(i) for i in range(len(TESTS_SH))])
 def test_reference_smoke_script_lines_parse_to_the_reference_namespace(line, want):
     ns = vars(cli.prepare_parser().parse_args(shlex.split(line)[1:]))
-    assert ns.pop('device') is None  # this build's only extra flag
+    assert ns.pop('device') is None  # this build's extra flags: the GPU ordinal, and the stranded-bulk extension (off)
+    assert ns.pop('bulk_strand_extension') is False
     assert ns == dict(DEFAULTS, **want)
 
 
