@@ -64,6 +64,12 @@ def test_script_and_refusals(tmp_path):
     assert open(out).read() == g['expected']['tsv']
     with pytest.raises(NotImplementedError):  # bulk --strand: te_count.py:58-59
         cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom', '--se', '--strand'])
+    # ... unless the extension is asked for by name: then the stranded table holds no more than the unstranded one
+    cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom', '--se', '--strand', '--bulk-strand-extension'])
+    plain = {ln.split('\t')[0]: int(ln.split('\t')[1]) for ln in g['expected']['tsv'].splitlines()}
+    stranded = {ln.split('\t')[0]: int(ln.split('\t')[1]) for ln in open(out).read().splitlines()}
+    assert stranded.keys() <= plain.keys() and all(stranded[k] <= plain[k] for k in stranded)
+    assert 0 < sum(stranded.values()) < sum(plain.values())
     with pytest.raises(AssertionError):       # --sc without --se: bin/te_count:109-110
         cli.main(['-i', aln, '-o', out, '-g', idx, '-m', 'custom', '--sc', '-w', 'x'])
     with pytest.raises(SystemExit):            # genome not built: bin/te_count:89-92
