@@ -143,10 +143,7 @@ struct Sink {
             add_n(name, (uint32_t)__builtin_popcountll(active & upto & ~((1ull << lane) - 1ull)));
         }
     }
-    bool mute;  // diagnostic ablation only (TEC_ABLATE): count nothing
-    uint32_t mute_lo, mute_hi;  // diagnostics: skip names in [mute_lo, mute_hi)
     __device__ __forceinline__ void add(uint32_t name) const {
-        if (mute || (name >= mute_lo && name < mute_hi)) return;
         if (aggregate)
             add_runs(name);
         else
@@ -320,9 +317,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, (flags & 32u) ? 32u : 0u,
-                    (flags & 16u) ? 32u : ((flags & 32u) ? 0xFFFFFFFFu : 0u)};
-    unsigned sinkhole = 0;  // keeps ablated loads alive
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0};
     const tec_entry* __restrict__ ent = idx.entries;
     const uint32_t sbit = (flags & kStrandedRun) ? 1u : 0u;  // see tec_bulk_set_stranded
     unsigned n_assigned = 0, n_lowq = 0, n_bad = 0, n_qc = 0, n_enh = 0;
@@ -347,11 +342,6 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
             ch[k] = __builtin_nontemporal_load(&chrom[ii]);
             un[k].p1 = __builtin_nontemporal_load(&p1[ii]);
             un[k].p2 = __builtin_nontemporal_load(&p2[ii]);
-        }
-        if (flags & 8u) {  // ablation: stream only
-#pragma unroll
-            for (int k = 0; k < U; ++k) sinkhole ^= fl[k] ^ mq[k] ^ (unsigned)ch[k] ^ (unsigned)un[k].p1 ^ (unsigned)un[k].p2;
-            continue;
         }
         // ---- stage 2
         uint32_t a0[U], a1[U], b0[U], b1[U];
@@ -407,12 +397,6 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
                              (unsigned)un[k].p1 == q1 * TEC_BUCKET_SIZE ||
                              (unsigned)un[k].p2 + 1u == q2 * TEC_BUCKET_SIZE;
         }
-        if (flags & 4u) {  // ablation: gathers but no walk
-#pragma unroll
-            for (int k = 0; k < U; ++k)
-                if (live[k]) sinkhole ^= (unsigned)ea[k].left ^ (unsigned)eb[k].right ^ a1[k] ^ b1[k];
-            continue;
-        }
         // ---- stage 4
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -431,7 +415,6 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
         }
     }
     store_hist(hist, words, slabs + (size_t)blockIdx.x * words);
-    if (sinkhole == 0xDEADBEEFu && n == 0) stats[7] = sinkhole;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
     // tallies: waves -> workgroup (LDS) -> five global adds per workgroup (see count_bulk_rec_kernel)
     __shared__ uint32_t tally[5];
@@ -581,7 +564,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) hist[w] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0, (flags & 2u) != 0, 0u, 0u};  // exact path only
+    const Sink sink{hist, k_lds, counts, (flags & 1u) != 0};  // exact path only
     // bucket cursors of the spill list sit behind the histogram in dynamic LDS
     const uint32_t spill_lo = spill_cap >> 24, slice_cap = spill_cap & 0xFFFFFFu;
     const uint32_t n_buckets = (!ALL_LDS && spill) ? ((idx.n_names + (1u << spill_lo) - 1u) >> spill_lo) : 0u;
@@ -591,7 +574,7 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
     __syncthreads();
     const FastSink<ALL_LDS> fast{hist, k_lds, counts, (!ALL_LDS && spill) ? spill : nullptr, slice_cap, spill_lo, cursors};
 #ifdef TEC_DIAGNOSTICS
-    const bool mute = (flags & 2u) != 0;  // TEC_ABLATE
+    const bool mute = (flags & 2u) != 0;  // (diagnostic build: count nothing)
     unsigned sinkhole = 0;                // keeps ablated loads alive
 #endif
     const tec_entry* __restrict__ ent = idx.entries;
@@ -1022,7 +1005,7 @@ int launch_count(tec_ctx* ctx, const UnitPtrs& u, uint64_t n) {
                           dim3(kBlock), (uint32_t)lds, ctx->s_compute, timed ? ev.start : (hipEvent_t) nullptr,
                           timed ? ev.stop : (hipEvent_t) nullptr, 0u, ctx->idx, u.chrom, u.p1, u.p2,
                           u.flag, u.mapq, n, ctx->mapq_min, ctx->d_counts, ctx->d_stats, k_lds, span,
-                          (uint32_t)ctx->aggregate | (uint32_t)ctx->ablate | (ctx->stranded ? kStrandedRun : 0u), slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
+                          (uint32_t)ctx->aggregate | (ctx->stranded ? kStrandedRun : 0u), slab, spilling ? ctx->d_spill : (uint32_t*)nullptr,
                           spill_cap | (spill_lo << 24), ctx->d_spill_counts);
     TEC_HIP(ctx, hipGetLastError());
     if (spilling) {
@@ -1065,7 +1048,6 @@ int tec_bulk_init(tec_ctx* ctx) {
     ctx->rec_ne_wanted = 3;  // inline entries per bin record (32-byte records)
     e = getenv("TEC_AGG");  // tuning knob: fold runs of equal names across lanes (sorted input)
     ctx->aggregate = e ? atoi(e) : 0;
-    ctx->ablate = 0;
     ctx->lds_bytes = 0u;  // LDS histogram bytes per workgroup: automatic
     ctx->time_every = 1;
     e = getenv("TEC_SPILL");  // 0: names beyond the LDS histogram are counted with global atomics (the round-1 path)

@@ -98,7 +98,6 @@ struct tec_ctx {
     bool force_mixed = false;
     int rec_ne_wanted = 3;  // inline entries per bin record asked for (TEC_REC_NE)
     int rec_ne = 0;         // ... of the resident index (0: no records, bin shift too wide)
-    int ablate = 0;  // diagnostics (TEC_ABLATE)
     uint32_t lds_bytes = 0;  // 0 = automatic
     int span_div = 8;
     unsigned char* noalloc_scratch = nullptr;  // device address of this GPU's copy of bulk.hip's file-scope scratch array
