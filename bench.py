@@ -115,7 +115,12 @@ def main():
             eng.bulk_submit_device(n_units, *run.ptrs)
         if world > 1:
             eng.bulk_sync()
-            dist.all_reduce(counts_t)  # RCCL sum over xGMI
+            if backend == 'nccl':
+                dist.all_reduce(counts_t)  # RCCL sum over xGMI
+            else:  # (the rehearsal backend moves host memory only: synchronous copies out and back)
+                host = counts_t.cpu()
+                dist.all_reduce(host)
+                counts_t.copy_(host)
             torch.cuda.synchronize()
         return eng.bulk_finish()
 
@@ -132,7 +137,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = eng.bulk_kernel_time()
