@@ -558,7 +558,9 @@ void stage_chunk(tec_gbam* g, Staged* st, uint64_t off, bool epilogue, uint32_t 
             (void)hipEventSynchronize(pc.done);
             pc.busy = false;
         }
-        const size_t win = (size_t)std::min<uint64_t>(g->piece_bytes, g->file_size - base);
+        // (no more than the chunk can still take: what is read beyond its last block is read again for the next chunk)
+        const uint64_t room = (uint64_t)cap_bytes - std::min<uint64_t>(cap_bytes, base > off ? base - off : 0) + kOverlap;
+        const size_t win = (size_t)std::min<uint64_t>(std::min<uint64_t>(g->piece_bytes, room), g->file_size - base);
         if (win + 32 > pc.cap) {
             if (pc.p) (void)hipHostFree(pc.p);
             pc.p = nullptr;
@@ -1244,6 +1246,12 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
     uint64_t processed = 0;  // chunks this thread is done with (rows extracted, tail moved on, compute stream drained)
     bool stop = false;
     uint64_t next_off = g->first_data_off;
+#ifdef TEC_GBAM_TRACE  // trace build (make EXTRA=-DTEC_GBAM_TRACE): when each chunk is staged / launched / processed
+    const double trace_t0 = now_s();
+#define GBAM_TRACE(what, k, n) fprintf(stderr, "[gbam %8.2f ms] chunk %llu %s (%llu)\n", (now_s() - trace_t0) * 1e3, (unsigned long long)(k), what, (unsigned long long)(n))
+#else
+#define GBAM_TRACE(what, k, n) (void)0
+#endif
     std::thread producer([&] {
         uint64_t off = next_off;
         for (uint64_t k = 0;; ++k) {
@@ -1255,7 +1263,9 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             }
             (void)hipSetDevice(ctx->device);
             Staged* st = &g->slots[slot];
+            GBAM_TRACE("slot free", k, slot);
             stage_chunk(g, st, off, false, g->chunk_blocks);
+            GBAM_TRACE("staged", k, st->desc.size());
             if (st->error.empty() && !st->desc.empty()) {
                 if (kCarryMax + st->inflated + 256 > g->d_infl2[slot].cap) {  // (an estimate fell short: see above)
                     std::unique_lock<std::mutex> lk(mu);
@@ -1302,7 +1312,9 @@ int run_decode(tec_gbam* g, const RunArgs& a, tec_gbam_report* rep) {
             break;
         }
         ChunkResult res;
+        GBAM_TRACE("taken", k, st->desc.size());
         rc = process_chunk(g, st, a, &rs, false, &res);
+        GBAM_TRACE("processed", k, res.n_records);
         if (rc) break;
         if (first_token_pending && res.first_pos != kNone) {
             uint64_t tok[2];
