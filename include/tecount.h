@@ -278,6 +278,11 @@ int tec_sc_adopt_copy(tec_ctx* ctx, int column, uint64_t dst_row, const void* d_
 int tec_sc_adopt_commit(tec_ctx* ctx);
 int tec_sc_host_row_bytes(tec_ctx* ctx, uint64_t* bytes);
 int tec_sc_part1_sort(tec_ctx* ctx, uint64_t* n_keys);
+/* How tec_sc_part1_sort ordered the survivors (the reference's `umis` dict and its sorted bundle lines,
+ * te_count.py:371-390, 464-473, need no such choice): *bits = length of the (barcode id, UMI) key string without the bits
+ * that are equal in every survivor, sorted in one or two radix rounds; 0 = the string was longer than 96 bits (or
+ * TEC_SC_SORT=columns) and the columns were sorted one by one.  Results do not depend on it. */
+int tec_sc_sort_key_bits(tec_ctx* ctx, uint32_t* bits);
 int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t* first_no_ub);
 /* Ordinal of the first surviving record whose UMI does not fit the 24-byte field (~0: none); after tec_sc_part1_sort.
  * (The reference keeps UMIs as Python strings of any length, te_count.py:420-427; this library refuses such a run.) */

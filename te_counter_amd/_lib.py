@@ -109,6 +109,7 @@ _SIGNATURES = {
     'tec_sc_adopt_copy': (C.c_int, [_p, C.c_int, _u64, C.c_void_p, _u64]),
     'tec_sc_adopt_commit': (C.c_int, [_p]),
     'tec_sc_host_row_bytes': (C.c_int, [_p, C.POINTER(_u64)]),
+    'tec_sc_sort_key_bits': (C.c_int, [_p, C.POINTER(C.c_uint32)]),
     'tec_sc_submit_device': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p]),
     'tec_bam_ref_name': (C.c_char_p, [_p, C.c_int]),
     'tec_bam_read': (C.c_int, [_p, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_u64)]),

@@ -76,8 +76,8 @@ enum { ST_QCFAIL = 0, ST_LOWQ, ST_BADBC, ST_SKIPCHROM, ST_NOCB, ST_NOUB, ST_LONG
 // freeing two dozen arrays of HBM costs more than the kernels of a small run), the next tec_sc_begin on that context
 // takes them over, tec_destroy frees them.  Nothing in them is read before it is written.
 struct ScBuffers {
-    dvec<uint64_t> wl;          // 3 words per barcode, big-endian packed, ascending
-    dvec<uint32_t> wl_table;    // open-addressing hash over wl: rank + 1, 0 = empty
+    dvec<uint64_t> wl_table;    // open-addressing hash of the whitelist, four words per slot: the barcode's three words
+                                // (big-endian packed) and its rank + 1, 0 = empty
     dvec<int32_t> cls_chrom;    // read-side chromosome class -> index chrom id (-1: not in index)
     dvec<uint8_t> cls_skip;     // '_' or 'alt' in the read-side chromosome string
     // survivors, in file order
@@ -103,6 +103,7 @@ struct ScBuffers {
     dvec<uint32_t> k32a, k32b;
     dvec<int32_t> s_klass, s_left, s_rite;
     dvec<uint8_t> ghead, ihead, counted;
+    dvec<uint4> rows;  // the survivors as 64-byte rows (four pieces each), built by part 1 for the one gather behind its sort
     // temporaries of parts 2 and 3, and their result: the sorted (cell << 32 | name) keys with their counts stay in HBM
     // until tec_sc_fetch takes them
     struct {
@@ -158,7 +159,7 @@ struct ScBuffers {
         if (pin_out) (void)hipHostFree(pin_out);
         pin_out = nullptr;
         pin_out_cap = 0;
-        wl.release(); wl_table.release(); cls_chrom.release(); cls_skip.release();
+        wl_table.release(); cls_chrom.release(); cls_skip.release();
         bcid.release(); u0.release(); u1.release(); u2.release(); rec.release();
         klass.release(); left.release(); rite.release(); stat.release();
         b_live.release(); b_scan.release(); b_bcid.release(); b_in.release(); b_in2.release(); tmp.release();
@@ -179,7 +180,7 @@ struct ScBuffers {
         s_u0.release(); s_u1.release(); s_u2.release(); k32a.release(); k32b.release();
         s_klass.release(); s_left.release(); s_rite.release(); ghead.release(); ihead.release();
         s_rec.release(); marks.release();
-        counted.release();
+        counted.release(); rows.release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         ev0 = ev1 = nullptr;
@@ -208,6 +209,7 @@ struct tec_sc_state : ScBuffers {
     uint64_t n_land = 0;         // rows the landing columns were sized for (tec_sc_adopt_begin)
     uint64_t host_row_bytes = 0; // bytes of survivor columns that went to host memory in this run (tec_sc_survivors_fetch)
     uint64_t kept_lines = 0, n_queries = 0, n_assigned = 0;
+    uint32_t sort_key_bits = 0;  // of part 1's key string; 0 = sorted column by column
     unsigned long long h_stat[ST_N] = {0};
     double gpu_ms = 0.0;
 };
@@ -256,16 +258,18 @@ __host__ __device__ __forceinline__ uint64_t wl_hash(uint64_t a, uint64_t b, uin
     return h ^ (h >> 32);
 }
 
-// Whitelist membership and rank (te_count.py:412,418): open-addressing table over the packed,
-// sorted whitelist; table[slot] = rank + 1, 0 = empty.  ~1.3 probes instead of a 20-step search.
-__device__ __forceinline__ int wl_find(const uint64_t* __restrict__ wl, const uint32_t* __restrict__ table,
-                                       uint32_t mask, uint64_t a, uint64_t b, uint64_t c) {
+// Whitelist membership and rank (te_count.py:412,418): open-addressing table of 32-byte slots {barcode words a, b, c,
+// rank + 1} (rank + 1 == 0: empty), so that a probe is ONE 32-byte access: with the barcodes in an array of their own the
+// probe was a table word and then, behind it, the barcode it pointed at -- two dependent random lines per record.
+__device__ __forceinline__ int wl_find(const uint4* __restrict__ table, uint32_t mask, uint64_t a, uint64_t b, uint64_t c) {
     uint32_t slot = (uint32_t)wl_hash(a, b, c) & mask;
     for (;;) {
-        const uint32_t v = table[slot];
-        if (v == 0) return -1;
-        const size_t i = (size_t)(v - 1);
-        if (wl[3 * i] == a && wl[3 * i + 1] == b && wl[3 * i + 2] == c) return (int)i;
+        const uint4 lo = table[2 * (size_t)slot], hi = table[2 * (size_t)slot + 1];
+        const uint64_t rank1 = (uint64_t)hi.z | ((uint64_t)hi.w << 32);
+        if (rank1 == 0) return -1;
+        if ((((uint64_t)lo.x | ((uint64_t)lo.y << 32)) == a) & (((uint64_t)lo.z | ((uint64_t)lo.w << 32)) == b) &
+            (((uint64_t)hi.x | ((uint64_t)hi.y << 32)) == c))
+            return (int)(rank1 - 1);
         slot = (slot + 1) & mask;
     }
 }
@@ -284,47 +288,53 @@ struct BlockTally {
         const unsigned long long m = __ballot(pred);
         if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&lds[k], (uint32_t)__builtin_popcountll(m));
     }
+    __device__ __forceinline__ void add_n(int k, uint32_t v) {  // per-lane counts: summed over the wave first
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lds[k], v);
+    }
     __device__ __forceinline__ void end(unsigned long long* const* dst) {
         __syncthreads();
         if (threadIdx.x < N && lds[threadIdx.x]) atomicAdd(dst[threadIdx.x], (unsigned long long)lds[threadIdx.x]);
     }
 };
 
-// te_count.py:394-433, in the reference's order.
-__global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* __restrict__ cls,
+// te_count.py:394-433, in the reference's order.  A fixed grid strides over the batch and every workgroup adds its four
+// tallies to the run's counters once, at its end: with a workgroup per 256 records a 4 M-record batch ended in 60 k
+// memory-side atomics on one line, which took longer than the batch's loads.
+__global__ __launch_bounds__(256) void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* __restrict__ cls,
                                  const uint16_t* __restrict__ flag, const uint8_t* __restrict__ mapq,
                                  const uint8_t* __restrict__ cb, const uint8_t* __restrict__ tagflags, int mapq_min,
-                                 const uint64_t* __restrict__ wl, const uint32_t* __restrict__ wl_table, uint32_t wl_mask,
+                                 const uint4* __restrict__ wl_table, uint32_t wl_mask,
                                  const uint8_t* __restrict__ cls_skip,
                                  uint32_t n_class, uint32_t* live, uint32_t* bcid_out, unsigned long long* stat) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t tally_lds[4];
     BlockTally<4> tally{tally_lds};
     tally.begin();
-    bool qc = false, lowq = false, badbc = false, skipc = false, ok = false;
-    if (i < n) {
+    uint32_t n_qc = 0, n_lowq = 0, n_badbc = 0, n_skipc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        bool ok = false;
         const unsigned fl = flag[i];
         const unsigned tf = tagflags[i];
         if (fl & (TEC_FLAG_UNMAPPED | TEC_FLAG_QCFAIL | TEC_FLAG_DUP)) {
-            qc = true;
+            ++n_qc;
         } else if ((int)mapq[i] < mapq_min) {
-            lowq = true;
+            ++n_lowq;
         } else if (!(tf & 1u)) {
             atomicMin(&stat[ST_NOCB], (unsigned long long)(rec_base + i));  // AssertionError('CB or CR tag not found!')
         } else {
             int id = -1;
             if (!(tf & 4u)) {  // bit 2: barcode longer than 24 bytes, cannot be on the whitelist
                 const uint8_t* p = cb + 24 * i;
-                id = wl_find(wl, wl_table, wl_mask, load_be64(p), load_be64(p + 8), load_be64(p + 16));
+                id = wl_find(wl_table, wl_mask, load_be64(p), load_be64(p + 8), load_be64(p + 16));
             }
             if (id < 0) {
-                badbc = true;
+                ++n_badbc;
             } else if (!(tf & 2u)) {
                 atomicMin(&stat[ST_NOUB], (unsigned long long)(rec_base + i));  // AssertionError('UB or UR tag not found!')
             } else {
                 const int c = cls[i];
                 if (c < 0 || (uint32_t)c >= n_class || cls_skip[c]) {
-                    skipc = true;
+                    ++n_skipc;
                 } else {
                     ok = true;
                     bcid_out[i] = (uint32_t)id;
@@ -336,10 +346,10 @@ __global__ void sc_filter_kernel(uint64_t n, uint64_t rec_base, const int32_t* _
         }
         live[i] = ok ? 1u : 0u;
     }
-    tally.add(0, qc);
-    tally.add(1, lowq);
-    tally.add(2, badbc);
-    tally.add(3, skipc);
+    tally.add_n(0, n_qc);
+    tally.add_n(1, n_lowq);
+    tally.add_n(2, n_badbc);
+    tally.add_n(3, n_skipc);
     unsigned long long* const dst[4] = {&stat[ST_QCFAIL], &stat[ST_LOWQ], &stat[ST_BADBC], &stat[ST_SKIPCHROM]};
     tally.end(dst);
 }
@@ -446,6 +456,117 @@ __global__ void gather_kernel(uint64_t n, const uint32_t* __restrict__ perm, con
 __global__ void iota_kernel(uint64_t n, uint32_t* p) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (uint32_t)i;
+}
+
+// Which UMI bits differ anywhere among the survivors: out6 = {OR of word 0, 1, 2, AND of word 0, 1, 2}.  A bit that is
+// the same in every UMI (the high bits of ASCII letters, the zero padding behind a 12-mer) cannot decide a comparison
+// and is left out of the sort key.
+__global__ __launch_bounds__(256) void umi_masks_kernel(uint64_t n, const uint64_t* __restrict__ u0, const uint64_t* __restrict__ u1,
+                                                        const uint64_t* __restrict__ u2, unsigned long long* out6) {
+    unsigned long long o0 = 0, o1 = 0, o2 = 0, a0 = ~0ull, a1 = ~0ull, a2 = ~0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {  // twelve loads in flight per lane
+        unsigned long long x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = __builtin_nontemporal_load(&u0[i + k * stride]);
+            y[k] = __builtin_nontemporal_load(&u1[i + k * stride]);
+            z[k] = __builtin_nontemporal_load(&u2[i + k * stride]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o0 |= x[k]; o1 |= y[k]; o2 |= z[k];
+            a0 &= x[k]; a1 &= y[k]; a2 &= z[k];
+        }
+    }
+    for (; i < n; i += stride) {
+        const unsigned long long x = u0[i], y = u1[i], z = u2[i];
+        o0 |= x; o1 |= y; o2 |= z;
+        a0 &= x; a1 &= y; a2 &= z;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        o0 |= __shfl_down(o0, off, 64); o1 |= __shfl_down(o1, off, 64); o2 |= __shfl_down(o2, off, 64);
+        a0 &= __shfl_down(a0, off, 64); a1 &= __shfl_down(a1, off, 64); a2 &= __shfl_down(a2, off, 64);
+    }
+    // waves -> workgroup in LDS -> six global atomics per workgroup (thousands of waves on one line of memory-side
+    // atomics would queue for longer than the pass itself takes)
+    __shared__ unsigned long long acc[6];
+    if (threadIdx.x < 6) acc[threadIdx.x] = threadIdx.x < 3 ? 0ull : ~0ull;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        atomicOr(&acc[0], o0); atomicOr(&acc[1], o1); atomicOr(&acc[2], o2);
+        atomicAnd(&acc[3], a0); atomicAnd(&acc[4], a1); atomicAnd(&acc[5], a2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicOr(&out6[threadIdx.x], acc[threadIdx.x]);
+    else if (threadIdx.x < 6)
+        atomicAnd(&out6[threadIdx.x], acc[threadIdx.x]);
+}
+
+// The sort key of part 1 as one bit string: barcode id, then the bits of the three UMI words that differ anywhere, most
+// significant first.  Dropping bits that are equal in every row keeps the order of any two rows.  The host cuts the
+// string into runs of adjacent source bits; no run crosses bit 64 of the string.
+constexpr int kMaxKeyRuns = 56;
+struct KeyRuns {
+    uint32_t n;
+    struct Run {
+        unsigned long long mask;  // of the run's width
+        uint8_t word, src, dst;   // source word (0..2 = UMI words, 3 = barcode id), first source bit, first bit in the string
+    } r[kMaxKeyRuns];
+};
+
+// One pass over the survivor columns (file order): the 64-byte row of every survivor and its key string (low 64 bits;
+// the bits above them, at most 32, when the string is longer).
+__global__ __launch_bounds__(256) void pack_rows_kernel(uint64_t n, const uint32_t* __restrict__ bcid, const uint64_t* __restrict__ u0,
+                                                        const uint64_t* __restrict__ u1, const uint64_t* __restrict__ u2,
+                                                        const uint64_t* __restrict__ rec, const int32_t* __restrict__ klass,
+                                                        const int32_t* __restrict__ left, const int32_t* __restrict__ rite,
+                                                        const KeyRuns kr, uint4* __restrict__ rows, uint64_t* __restrict__ key_lo,
+                                                        uint32_t* __restrict__ key_hi) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t a = u0[i], b = u1[i], c = u2[i], o = rec[i];
+    const uint32_t bc = bcid[i];
+    uint4* row = rows + 4 * i;
+    row[0] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    row[1] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)o, (uint32_t)(o >> 32));
+    row[2] = make_uint4(bc, (uint32_t)klass[i], (uint32_t)left[i], (uint32_t)rite[i]);
+    row[3] = make_uint4(0u, 0u, 0u, 0u);
+    uint64_t lo = 0, hi = 0;
+    for (uint32_t k = 0; k < kr.n; ++k) {  // (wave-uniform: the runs come from the kernel arguments)
+        const uint32_t w = kr.r[k].word, src = kr.r[k].src, dst = kr.r[k].dst;
+        const uint64_t v = w == 0 ? a : w == 1 ? b : w == 2 ? c : (uint64_t)bc;
+        const uint64_t f = (v >> src) & kr.r[k].mask;
+        if (dst < 64u)
+            lo |= f << dst;
+        else
+            hi |= f << (dst - 64u);
+    }
+    key_lo[i] = lo;
+    if (key_hi) key_hi[i] = (uint32_t)hi;
+}
+
+// The sorted views of part 1: row perm[i] of the packed survivors (one 64-byte piece of one line) spread over the
+// eight sorted columns.  (Eight column gathers pulled eight lines per survivor.)
+__global__ __launch_bounds__(256) void gather_rows_kernel(uint64_t n, const uint32_t* __restrict__ perm, const uint4* __restrict__ rows,
+                                                          uint32_t* __restrict__ s_bcid, uint64_t* __restrict__ s_u0,
+                                                          uint64_t* __restrict__ s_u1, uint64_t* __restrict__ s_u2,
+                                                          uint64_t* __restrict__ s_rec, int32_t* __restrict__ s_klass,
+                                                          int32_t* __restrict__ s_left, int32_t* __restrict__ s_rite) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* row = rows + 4 * (uint64_t)perm[i];
+    const uint4 q0 = row[0], q1 = row[1], q2 = row[2];
+    s_u0[i] = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
+    s_u1[i] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+    s_u2[i] = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
+    s_rec[i] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+    s_bcid[i] = q2.x;
+    s_klass[i] = (int32_t)q2.y;
+    s_left[i] = (int32_t)q2.z;
+    s_rite[i] = (int32_t)q2.w;
 }
 
 __global__ void ghead_kernel(uint64_t n, const uint32_t* __restrict__ bc, const uint64_t* __restrict__ u0,
@@ -883,7 +1004,7 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
     s->bundle_keys = bundle_keys;
     s->n_wl = n_whitelist;
     s->n_class = n_class;
-    const bool same_wl = s->wl_src && s->wl_src->size() == 24 * (size_t)n_whitelist && s->wl.p && s->wl_table.p &&
+    const bool same_wl = s->wl_src && s->wl_src->size() == 24 * (size_t)n_whitelist && s->wl_table.p &&
                          memcmp(s->wl_src->data(), whitelist24, 24 * (size_t)n_whitelist) == 0;
     if (same_wl) {
         s->wl_mask = s->wl_src_mask;
@@ -902,20 +1023,22 @@ extern "C" int tec_sc_begin(tec_ctx* ctx, int stranded, int mapq_min, uint32_t n
             if (!(a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[2] < b[2])))))
                 return tec_fail(ctx, TEC_EINVAL, "tec_sc_begin: whitelist must be strictly ascending (entry %zu)", i);
         }
-        SC_HIP(s->wl.reserve(packed.size()));
-        SC_HIP(hipMemcpy(s->wl.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
         {
             uint64_t cap = 16;
             while (cap < 2ull * n_whitelist) cap <<= 1;
-            std::vector<uint32_t> table(cap, 0u);
+            std::vector<uint64_t> table(4 * cap, 0ull);
             const uint32_t mask = (uint32_t)(cap - 1);
             for (uint32_t i = 0; i < n_whitelist; ++i) {
-                uint32_t slot = (uint32_t)wl_hash(packed[3 * (size_t)i], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2]) & mask;
-                while (table[slot]) slot = (slot + 1) & mask;
-                table[slot] = i + 1;
+                const uint64_t* k = &packed[3 * (size_t)i];
+                uint32_t slot = (uint32_t)wl_hash(k[0], k[1], k[2]) & mask;
+                while (table[4 * (size_t)slot + 3]) slot = (slot + 1) & mask;
+                table[4 * (size_t)slot] = k[0];
+                table[4 * (size_t)slot + 1] = k[1];
+                table[4 * (size_t)slot + 2] = k[2];
+                table[4 * (size_t)slot + 3] = (uint64_t)i + 1;
             }
-            SC_HIP(s->wl_table.reserve(cap));
-            SC_HIP(hipMemcpy(s->wl_table.p, table.data(), cap * 4, hipMemcpyHostToDevice));
+            SC_HIP(s->wl_table.reserve(table.size()));
+            SC_HIP(hipMemcpy(s->wl_table.p, table.data(), table.size() * 8, hipMemcpyHostToDevice));
             s->wl_mask = mask;
         }
         s->wl_src = std::make_shared<std::vector<uint8_t>>(whitelist24, whitelist24 + 24 * (size_t)n_whitelist);
@@ -1010,8 +1133,8 @@ int sc_ingest(tec_ctx* ctx, tec_sc_state* s, uint64_t n, const int32_t* d_cls, c
     SC_HIP(s->rite.reserve(need, true, std::min(used, s->rite.cap), floor));
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, st);
-    hipLaunchKernelGGL(sc_filter_kernel, dim3(grid_for(n)), dim3(kB), 0, st, n, s->n_seen, d_cls, d_flag, d_mapq, d_cb, d_tf,
-                       s->mapq_min, s->wl.p, s->wl_table.p, s->wl_mask, s->cls_skip.p, s->n_class, s->b_live.p, s->b_bcid.p,
+    hipLaunchKernelGGL(sc_filter_kernel, dim3(std::min(grid_for(n), 2048u)), dim3(kB), 0, st, n, s->n_seen, d_cls, d_flag, d_mapq, d_cb, d_tf,
+                       s->mapq_min, reinterpret_cast<const uint4*>(s->wl_table.p), s->wl_mask, s->cls_skip.p, s->n_class, s->b_live.p, s->b_bcid.p,
                        s->stat.p);
     int rc = scan_u32(ctx, s, s->b_live.p, s->b_scan.p, n, false, rocprim::plus<uint32_t>());
     if (rc) return rc;
@@ -1177,22 +1300,50 @@ int tec_sc_expect_records(tec_ctx* ctx, uint64_t n_records) {
 namespace {
 
 // Part 1, step 1: stable LSD radix sort of a permutation by (bcid, u0, u1, u2); sorted views; key heads.
-int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
+// The key string of part 1 (see KeyRuns) from the bits that differ: UMI word 2 lowest, then word 1, word 0, the barcode
+// id on top.  False when the string is longer than 96 bits or needs more runs than KeyRuns holds (UMIs of many arbitrary
+// bytes): the caller then sorts column by column.
+bool build_key_runs(const unsigned long long vary[3], unsigned bc_bits, KeyRuns* kr, unsigned* total_bits) {
+    unsigned dst = 0;
+    kr->n = 0;
+    auto push = [&](unsigned word, unsigned src, unsigned width) {
+        while (width) {
+            unsigned take = width;
+            if (dst < 64u && dst + take > 64u) take = 64u - dst;  // no run crosses bit 64 of the string
+            if (kr->n == (uint32_t)kMaxKeyRuns || dst + take > 96u) return false;
+            KeyRuns::Run& r = kr->r[kr->n++];
+            r.mask = take == 64u ? ~0ull : (1ull << take) - 1ull;
+            r.word = (uint8_t)word;
+            r.src = (uint8_t)src;
+            r.dst = (uint8_t)dst;
+            src += take;
+            dst += take;
+            width -= take;
+        }
+        return true;
+    };
+    for (int w = 2; w >= 0; --w) {
+        unsigned long long m = vary[w];
+        while (m) {
+            const unsigned first = (unsigned)__builtin_ctzll(m);
+            const unsigned long long t = m >> first;
+            const unsigned len = t == ~0ull ? 64u : (unsigned)__builtin_ctzll(~t);
+            if (!push((unsigned)w, first, len)) return false;
+            m = len == 64u ? 0ull : m & ~(((1ull << len) - 1ull) << first);
+        }
+    }
+    if (!push(3u, 0u, bc_bits)) return false;
+    *total_bits = dst;
+    return true;
+}
+
+// The column-by-column form of part 1's sort: one stable radix round per UMI word that has bits set (least significant
+// word first) and one for the barcode id, each behind a gather of its keys, then eight gathers for the sorted views.
+// Any UMI sorts this way; sc_part1_sort uses it when the key string does not fit (or under TEC_SC_SORT=columns).
+int sc_sort_by_columns(tec_ctx* ctx, tec_sc_state* s) {
     hipStream_t st = ctx->s_compute;
-    SC_HIP(hipStreamSynchronize(st));
-    SC_HIP(hipMemcpy(s->h_stat, s->stat.p, sizeof s->h_stat, hipMemcpyDeviceToHost));
-    s->sorted = true;
-    s->bounds.clear();
     const uint64_t N = s->n_live;
-    if (N == 0) return TEC_OK;
     const unsigned g = grid_for(N);
-    SC_HIP(s->perm.reserve(N));
-    SC_HIP(s->perm2.reserve(N));
-    SC_HIP(s->k64a.reserve(N));
-    SC_HIP(s->k64b.reserve(N));
-    SC_HIP(s->k32a.reserve(N));
-    SC_HIP(s->k32b.reserve(N));
-    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p);
     const uint64_t* words[3] = {s->u2.p, s->u1.p, s->u0.p};
     const unsigned long long masks[3] = {s->h_stat[ST_OR2], s->h_stat[ST_OR1], s->h_stat[ST_OR0]};
     for (int w = 0; w < 3; ++w) {
@@ -1211,15 +1362,6 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
         std::swap(s->perm.p, s->perm2.p);
         std::swap(s->perm.cap, s->perm2.cap);
     }
-    // ---- sorted views
-    SC_HIP(s->s_bcid.reserve(N));
-    SC_HIP(s->s_u0.reserve(N));
-    SC_HIP(s->s_u1.reserve(N));
-    SC_HIP(s->s_u2.reserve(N));
-    SC_HIP(s->s_rec.reserve(N));
-    SC_HIP(s->s_klass.reserve(N));
-    SC_HIP(s->s_left.reserve(N));
-    SC_HIP(s->s_rite.reserve(N));
     hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->bcid.p, s->s_bcid.p);
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u0.p, s->s_u0.p);
     hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->u1.p, s->s_u1.p);
@@ -1231,6 +1373,78 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->klass.p, s->s_klass.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->left.p, s->s_left.p);
     hipLaunchKernelGGL(gather_kernel<int32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->rite.p, s->s_rite.p);
+    return TEC_OK;
+}
+
+// Part 1, step 1: the survivors ordered by (barcode id, UMI), records of one key in file order (a stable sort of rows
+// that are in file order).  One streaming pass packs every survivor into a 64-byte row and its key into a bit string
+// without the bits that are equal in all rows (10x UMIs: 12 letters of ACGT differ in 4 bits each; with a 20-bit
+// barcode id the string has 68 bits against the 212 of the plain columns); a radix sort of the low 64 bits with the row
+// number as its value, one more round over the bits above them, and ONE gather of the rows into the sorted columns.
+int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
+    hipStream_t st = ctx->s_compute;
+    SC_HIP(hipStreamSynchronize(st));
+    SC_HIP(hipMemcpy(s->h_stat, s->stat.p, sizeof s->h_stat, hipMemcpyDeviceToHost));
+    s->sorted = true;
+    s->bounds.clear();
+    const uint64_t N = s->n_live;
+    if (N == 0) return TEC_OK;
+    const unsigned g = grid_for(N);
+    SC_HIP(s->perm.reserve(N));
+    SC_HIP(s->perm2.reserve(N));
+    SC_HIP(s->k64a.reserve(N));
+    SC_HIP(s->k64b.reserve(N));
+    SC_HIP(s->k32a.reserve(N));
+    SC_HIP(s->k32b.reserve(N));
+    SC_HIP(s->s_bcid.reserve(N));
+    SC_HIP(s->s_u0.reserve(N));
+    SC_HIP(s->s_u1.reserve(N));
+    SC_HIP(s->s_u2.reserve(N));
+    SC_HIP(s->s_rec.reserve(N));
+    SC_HIP(s->s_klass.reserve(N));
+    SC_HIP(s->s_left.reserve(N));
+    SC_HIP(s->s_rite.reserve(N));
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p);
+    const char* how = getenv("TEC_SC_SORT");  // "columns": the column-by-column rounds for every input
+    bool by_rows = !(how && !strcmp(how, "columns"));
+    KeyRuns kr;
+    unsigned key_bits = 0;
+    if (by_rows) {
+        // the bits that differ among the survivors' UMIs
+        SC_HIP(s->marks.reserve(64));
+        const unsigned long long init[6] = {0ull, 0ull, 0ull, ~0ull, ~0ull, ~0ull};
+        unsigned long long h[6];
+        SC_HIP(hipMemcpyAsync(s->marks.p, init, sizeof init, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(umi_masks_kernel, dim3(std::min(g, 1024u)), dim3(256), 0, st, N, s->u0.p, s->u1.p, s->u2.p,
+                           reinterpret_cast<unsigned long long*>(s->marks.p));
+        SC_HIP(hipMemcpyAsync(h, s->marks.p, sizeof h, hipMemcpyDeviceToHost, st));
+        SC_HIP(hipStreamSynchronize(st));
+        const unsigned long long vary[3] = {h[0] & ~h[3], h[1] & ~h[4], h[2] & ~h[5]};
+        by_rows = build_key_runs(vary, bits_for(s->n_wl), &kr, &key_bits);
+    }
+    s->sort_key_bits = by_rows ? key_bits : 0u;
+    if (!by_rows) {
+        int rc = sc_sort_by_columns(ctx, s);
+        if (rc) return rc;
+    } else {
+        SC_HIP(s->rows.reserve(4 * N));
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(g), dim3(256), 0, st, N, s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p, s->klass.p,
+                           s->left.p, s->rite.p, kr, s->rows.p, s->k64a.p, key_bits > 64u ? s->k32a.p : nullptr);
+        int rc = sort_pairs(ctx, s, s->k64a.p, s->k64b.p, s->perm.p, s->perm2.p, N, 0, std::min(key_bits, 64u));
+        if (rc) return rc;
+        std::swap(s->perm.p, s->perm2.p);
+        std::swap(s->perm.cap, s->perm2.cap);
+        if (key_bits > 64u) {
+            hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->k32a.p, s->k32b.p);
+            rc = sort_pairs(ctx, s, s->k32b.p, s->k32a.p, s->perm.p, s->perm2.p, N, 0, key_bits - 64u);
+            if (rc) return rc;
+            std::swap(s->perm.p, s->perm2.p);
+            std::swap(s->perm.cap, s->perm2.cap);
+        }
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(g), dim3(256), 0, st, N, s->perm.p, s->rows.p, s->s_bcid.p, s->s_u0.p, s->s_u1.p,
+                           s->s_u2.p, s->s_rec.p, s->s_klass.p, s->s_left.p, s->s_rite.p);
+    }
+    SC_HIP(hipGetLastError());
     // ---- keys (groups)
     SC_HIP(s->ghead.reserve(N));
     SC_HIP(s->gid.reserve(N));
@@ -1581,6 +1795,13 @@ extern "C" int tec_sc_part1_sort(tec_ctx* ctx, uint64_t* n_keys) {
 
 /* ordinals (ST_NOCB / ST_NOUB) of the first record that lacks a barcode / UMI tag, ~0 if none: the
  * reference dies at the smaller one (te_count.py:409, 426); valid after tec_sc_part1_sort */
+extern "C" int tec_sc_sort_key_bits(tec_ctx* ctx, uint32_t* bits) {
+    if (!ctx || !ctx->sc || !bits) return tec_fail(ctx, TEC_ESTATE, "tec_sc_sort_key_bits: no single-cell run");
+    if (!ctx->sc->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_sort_key_bits: call tec_sc_part1_sort first");
+    *bits = ctx->sc->sort_key_bits;
+    return TEC_OK;
+}
+
 extern "C" int tec_sc_missing_tags(tec_ctx* ctx, uint64_t* first_no_cb, uint64_t* first_no_ub) {
     if (!ctx || !ctx->sc || !ctx->sc->sorted) return tec_fail(ctx, TEC_ESTATE, "tec_sc_missing_tags: call tec_sc_part1_sort first");
     tec_sc_state* s = ctx->sc;

@@ -294,6 +294,12 @@ class Engine:
         self._check(self._lib.tec_sc_part1_sort(self._ctx, C.byref(n)))
         return int(n.value)
 
+    def sc_sort_key_bits(self):
+        """Bits of part 1's sort key string (0: the columns were sorted one by one); after the sort."""
+        b = C.c_uint32()
+        self._check(self._lib.tec_sc_sort_key_bits(self._ctx, C.byref(b)))
+        return int(b.value)
+
     def sc_missing_tags(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._lib.tec_sc_missing_tags(self._ctx, C.byref(a), C.byref(b)))

@@ -85,6 +85,7 @@ def run_parts(eng, world, n_records_local, bundle_keys, maxcells, pad):
     else:
         out = eng.sc_part23(selected)
     st = eng.sc_stats()
+    key_bits = eng.sc_sort_key_bits() if hasattr(eng, 'sc_sort_key_bits') else None
     eng.sc_end()
     # ---- merge (cells are disjoint over the ranks)
     res = {'total_records': total, 'raw_ids': ids, 'raw_counts': cnt, 'selected': selected,
@@ -107,5 +108,6 @@ def run_parts(eng, world, n_records_local, bundle_keys, maxcells, pad):
     summed['keys'] = _dist.world_sum(world, st['keys'])
     summed['bundles'] = len(bounds) + 1 if summed['survivors'] else 0
     summed['kept_lines'] = res['kept_lines']
+    summed['sort_key_bits'] = key_bits  # this rank's: how part 1 ordered its survivors (0 = column by column)
     res['stats'] = summed
     return res

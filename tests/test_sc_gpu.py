@@ -82,6 +82,29 @@ def test_random_vs_oracle(seed, strand, thr, tmp_path):
     assert (tsv, freq) == orc.format_sc_tsv(want_res, want_bc, 25)
 
 
+@pytest.mark.parametrize('umi_len,env,form', [(10, {}, 'one round'), (14, {}, 'two rounds'), (24, {}, 'columns'),
+                                              (10, {'TEC_SC_SORT': 'columns'}, 'columns')])
+@pytest.mark.parametrize('thr', [10 ** 7, 450])
+def test_every_form_of_the_part1_sort(umi_len, env, form, thr, tmp_path, monkeypatch):
+    """Part 1 orders the survivors by (barcode, UMI) through a key string without the bits that are equal in all of
+    them: up to 64 bits in one radix round, up to 96 in two, beyond that (or on request) column by column.  All three
+    forms must give the reference's result (te_count.py:371-476: the dict keyed by 'CB-UB' and its sorted bundles)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    types = ['protein_coding', 'lncRNA', 'TE', 'TE', 'snRNA', 'enhancer', 'miRNA']
+    feats = dg.make_features(77, 1200, span=250000, types=types)
+    wl = dg.make_whitelist(77, 300)
+    recs = dg.make_sc_records(78, 12000, wl, feats, span=250000, n_cells=40, umi_len=umi_len)
+    want_res, want_bc, want_total = orc.sc_count(feats, recs, wl, 20, strand=True, bundle_threshold=thr)
+    m, res, tsv, freq = run_sc(FlatIndex.from_features(feats), recs, wl, 20, True, 20, thr, tmp_path, batch_size=2999)
+    bits = m.stats['sort_key_bits']
+    assert {'one round': 0 < bits <= 64, 'two rounds': 64 < bits <= 96, 'columns': bits == 0}[form], bits
+    assert m.total_reads == want_total
+    assert list(m.barcodes.items()) == list(want_bc.items())
+    assert res == want_res
+    assert (tsv, freq) == orc.format_sc_tsv(want_res, want_bc, 20)
+
+
 @pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('name', ['sc_rand21_strand_multibundle', 'sc_rand22_nostrand_multibundle', 'sc_topcells_binding_multibundle',
                                   'sc_rand22_strand', 'sc_degenerate_boundary'])
