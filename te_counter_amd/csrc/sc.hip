@@ -716,17 +716,18 @@ __global__ void presence_mark_kernel(uint64_t n, const uint32_t* __restrict__ pr
 //   - the previous line of the bundle has the same barcode, or
 //   - there is an earlier barcode p with lines in this bundle (else this is the bundle's first line,
 //     which the reader never emits) and no selected barcode lies in [p, barcode).
-__global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_rec, const uint32_t* __restrict__ bc,
+__global__ __launch_bounds__(256) void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_rec, const uint32_t* __restrict__ bc,
                             const uint32_t* __restrict__ epoch, const uint32_t* __restrict__ sel,
                             const uint32_t* __restrict__ selprefix, const uint32_t* __restrict__ gid,
                             const uint32_t* __restrict__ pred, uint32_t n_wl, uint8_t* kept_rec, uint32_t* firstkept,
                             unsigned long long* n_kept) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (a fixed grid strides over the lines: one add of the kept count per workgroup, see sc_filter_kernel)
     __shared__ uint32_t tally_lds[1];
     BlockTally<1> tally{tally_lds};
     tally.begin();
-    bool k = false;
-    if (j < n_lines) {
+    uint32_t n_k = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_lines; j += (uint64_t)gridDim.x * blockDim.x) {
+        bool k = false;
         const uint32_t i = line_rec[j];
         const uint32_t b = bc[i], e = epoch[i];
         if (sel[b]) {
@@ -745,9 +746,12 @@ __global__ void kept_kernel(uint64_t n_lines, const uint32_t* __restrict__ line_
             }
         }
         kept_rec[i] = k;
-        if (k) atomicMin(&firstkept[gid[i]], i);
+        if (k) {
+            atomicMin(&firstkept[gid[i]], i);
+            ++n_k;
+        }
     }
-    tally.add(0, k);
+    tally.add_n(0, n_k);
     unsigned long long* const dst[1] = {n_kept};
     tally.end(dst);
 }
@@ -805,18 +809,25 @@ __device__ __forceinline__ void sc_range(const tec_index_dev& idx, int chrom, in
 // Part 3 for one (cell, class, left, rite).  EMIT=false: returns the number of (cell, name)
 // increments; EMIT=true: writes them.  Also bumps the per-cell "mapped to something" counter.
 template <bool EMIT>
-__global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* __restrict__ qrec,
+__global__ __launch_bounds__(256) void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* __restrict__ qrec,
                                 const uint32_t* __restrict__ bc, const int32_t* __restrict__ klass,
                                 const int32_t* __restrict__ left, const int32_t* __restrict__ rite,
                                 const int32_t* __restrict__ cls_chrom, int stranded, uint32_t* n_emit,
                                 const uint32_t* __restrict__ emit_off, uint64_t* keys, uint32_t* cellhits,
                                 unsigned long long* stat, unsigned long long* n_assigned) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // tallies per block (see BlockTally): [0] assigned, [1] hits on a feature without a strand
+    // tallies per block (see BlockTally): [0] assigned, [1] hits on a feature without a strand.  A fixed grid strides
+    // over the queries in whole-wave steps (every lane of a wave makes the same number of trips: the per-cell adds
+    // below are folded over the wave), and the tallies go to memory once per workgroup.
     __shared__ uint32_t tally_lds[2];
     BlockTally<2> tally{tally_lds};
     if (!EMIT) tally.begin();
-    bool did_assign = false, did_nostrand = false;
+    uint32_t n_assign = 0, n_nostrand = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t trips = (nq + stride - 1) / stride;
+    for (uint64_t trip = 0; trip < trips; ++trip) {
+    const uint64_t t = trip * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool did_hit = false;
+    uint32_t hit_bc = 0;
     if (t < nq) {
     const uint32_t i = qrec[t];
     const int kl = klass[i];
@@ -854,13 +865,14 @@ __global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* 
             }
         if (classes) {
             if (!EMIT) {
-                atomicAdd(&cellhits[bc[i]], 1u);  // self.barcodes[barcode] += 1 (te_count.py:653-655)
-                did_nostrand = nostrand;  // KeyError: 'strand' (te_count.py:661)
+                did_hit = true;  // self.barcodes[barcode] += 1 (te_count.py:653-655), added below
+                hit_bc = bc[i];
+                n_nostrand += nostrand ? 1u : 0u;  // KeyError: 'strand' (te_count.py:661)
             }
             const bool gene = classes & (1u << TEC_CLASS_GENE);
             const bool other = classes & ((1u << TEC_CLASS_TE) | (1u << TEC_CLASS_ENHANCER));
             if (gene || other) {
-                did_assign = true;
+                ++n_assign;
                 const uint32_t rs = (uint32_t)(kl & 1);
                 const uint64_t cell = (uint64_t)bc[i] << 32;
                 uint32_t last = 0xFFFFFFFFu;
@@ -902,8 +914,21 @@ __global__ void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* 
     if (!EMIT) n_emit[t] = emitted;
     }
     if (!EMIT) {
-        tally.add(0, did_assign);
-        tally.add(1, did_nostrand);
+        // the queries are in barcode order, so a wave mostly sees one or two cells: one add per distinct cell of the
+        // wave instead of one memory-side atomic per query on a few thousand hot words
+        uint64_t todo = __builtin_amdgcn_ballot_w64(did_hit);
+        while (todo) {  // wave-uniform
+            const int lead = __builtin_ctzll(todo);
+            const uint32_t bl = (uint32_t)__shfl((int)hit_bc, lead, 64);
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(did_hit && hit_bc == bl);
+            if ((int)(threadIdx.x & 63u) == lead) atomicAdd(&cellhits[bl], (uint32_t)__builtin_popcountll(mask));
+            todo &= ~mask;
+        }
+    }
+    }
+    if (!EMIT) {
+        tally.add_n(0, n_assign);
+        tally.add_n(1, n_nostrand);
         unsigned long long* const dst[2] = {n_assigned, &stat[ST_NOSTRAND]};
         tally.end(dst);
     }
@@ -2094,7 +2119,7 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
     SC_TRY(hipMemsetAsync(kept_rec.p, 0, N, st));
     SC_TRY(hipMemsetAsync(firstkept.p, 0xFF, ((size_t)s->n_groups + 1) * 4, st));
     SC_TRY(hipMemsetAsync(scal.p, 0, 4 * 8, st));
-    hipLaunchKernelGGL(kept_kernel, dim3(grid_for(n_lines)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
+    hipLaunchKernelGGL(kept_kernel, dim3(std::min(grid_for(n_lines), 4096u)), dim3(kB), 0, st, n_lines, lines.p, s->s_bcid.p, s->s_epoch.p,
                        sel.p, selprefix.p, s->gid.p, pred.p, s->n_wl, kept_rec.p, firstkept.p, scal.p);
     // ---- part 3 queries
     SC_TRY(qflag.reserve(N));
@@ -2122,7 +2147,7 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
     SC_TRY(emoff.reserve(nq));
     SC_TRY(cellhits.reserve(s->n_wl));
     SC_TRY(hipMemsetAsync(cellhits.p, 0, (size_t)s->n_wl * 4, st));
-    hipLaunchKernelGGL(sc_query_kernel<false>, dim3(grid_for(nq)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
+    hipLaunchKernelGGL(sc_query_kernel<false>, dim3(std::min(grid_for(nq), 4096u)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
                        s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, nemit.p, (const uint32_t*)nullptr,
                        (uint64_t*)nullptr, cellhits.p, s->stat.p, scal.p + 1);
     SC_RC(scan_u32(ctx, s, nemit.p, emoff.p, nq, false, rocprim::plus<uint32_t>()));
@@ -2156,7 +2181,7 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
         }
         SC_TRY(keys.reserve(n_keys));
         SC_TRY(keys2.reserve(n_keys));
-        hipLaunchKernelGGL(sc_query_kernel<true>, dim3(grid_for(nq)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
+        hipLaunchKernelGGL(sc_query_kernel<true>, dim3(std::min(grid_for(nq), 4096u)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
                            s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, (uint32_t*)nullptr, emoff.p,
                            keys.p, (uint32_t*)nullptr, s->stat.p, scal.p + 1);
         hipLaunchKernelGGL(map_names_kernel, dim3(grid_for(n_keys)), dim3(kB), 0, st, n_keys, keys.p, ctx->d_int2ext);
