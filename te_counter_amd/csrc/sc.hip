@@ -458,12 +458,24 @@ __global__ void iota_kernel(uint64_t n, uint32_t* p) {
     if (i < n) p[i] = (uint32_t)i;
 }
 
-// Which UMI bits differ anywhere among the survivors: out6 = {OR of word 0, 1, 2, AND of word 0, 1, 2}.  A bit that is
-// the same in every UMI (the high bits of ASCII letters, the zero padding behind a 12-mer) cannot decide a comparison
-// and is left out of the sort key.
+// Which UMI bits differ anywhere among the survivors: out8 = {OR of word 0, 1, 2, AND of word 0, 1, 2, "every UMI byte
+// is NUL or one of A C G N T" (all ones while true), which of those six occur (bit = the byte's low five bits)}.  A bit
+// that is the same in every UMI (the high bits of ASCII letters, the zero padding behind a 12-mer) cannot decide a
+// comparison and is left out of the sort key; a byte position of the six-symbol alphabet takes its symbol's rank.
+constexpr uint32_t kUmiLetters = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 14) | (1u << 20);  // 'A' 'C' 'G' 'N' 'T' & 31
+__device__ __forceinline__ void umi_alphabet(unsigned long long w, bool& ok, uint32_t& seen) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t b = (uint32_t)(w >> (8 * k)) & 0xFFu, lo = b & 31u;
+        ok = ok & ((b == 0u) | (((b >> 5) == 2u) & (((kUmiLetters >> lo) & 1u) != 0u)));
+        seen |= 1u << lo;
+    }
+}
 __global__ __launch_bounds__(256) void umi_masks_kernel(uint64_t n, const uint64_t* __restrict__ u0, const uint64_t* __restrict__ u1,
-                                                        const uint64_t* __restrict__ u2, unsigned long long* out6) {
+                                                        const uint64_t* __restrict__ u2, unsigned long long* out8) {
     unsigned long long o0 = 0, o1 = 0, o2 = 0, a0 = ~0ull, a1 = ~0ull, a2 = ~0ull;
+    bool ok = true;
+    uint32_t seen = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + 3 * stride < n; i += 4 * stride) {  // twelve loads in flight per lane
@@ -478,42 +490,57 @@ __global__ __launch_bounds__(256) void umi_masks_kernel(uint64_t n, const uint64
         for (int k = 0; k < 4; ++k) {
             o0 |= x[k]; o1 |= y[k]; o2 |= z[k];
             a0 &= x[k]; a1 &= y[k]; a2 &= z[k];
+            umi_alphabet(x[k], ok, seen);
+            umi_alphabet(y[k], ok, seen);
+            if (z[k]) umi_alphabet(z[k], ok, seen);  // (UMIs of at most 16 bytes: all NUL)
         }
     }
     for (; i < n; i += stride) {
         const unsigned long long x = u0[i], y = u1[i], z = u2[i];
         o0 |= x; o1 |= y; o2 |= z;
         a0 &= x; a1 &= y; a2 &= z;
+        umi_alphabet(x, ok, seen);
+        umi_alphabet(y, ok, seen);
+        umi_alphabet(z, ok, seen);
     }
+    unsigned long long conform = ok ? ~0ull : 0ull, pres = seen;
     for (int off = 32; off > 0; off >>= 1) {
         o0 |= __shfl_down(o0, off, 64); o1 |= __shfl_down(o1, off, 64); o2 |= __shfl_down(o2, off, 64);
         a0 &= __shfl_down(a0, off, 64); a1 &= __shfl_down(a1, off, 64); a2 &= __shfl_down(a2, off, 64);
+        conform &= __shfl_down(conform, off, 64);
+        pres |= __shfl_down(pres, off, 64);
     }
-    // waves -> workgroup in LDS -> six global atomics per workgroup (thousands of waves on one line of memory-side
+    // waves -> workgroup in LDS -> eight global atomics per workgroup (thousands of waves on one line of memory-side
     // atomics would queue for longer than the pass itself takes)
-    __shared__ unsigned long long acc[6];
-    if (threadIdx.x < 6) acc[threadIdx.x] = threadIdx.x < 3 ? 0ull : ~0ull;
+    __shared__ unsigned long long acc[8];
+    if (threadIdx.x < 8) acc[threadIdx.x] = (threadIdx.x < 3 || threadIdx.x == 7) ? 0ull : ~0ull;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
         atomicOr(&acc[0], o0); atomicOr(&acc[1], o1); atomicOr(&acc[2], o2);
         atomicAnd(&acc[3], a0); atomicAnd(&acc[4], a1); atomicAnd(&acc[5], a2);
+        atomicAnd(&acc[6], conform);
+        atomicOr(&acc[7], pres);
     }
     __syncthreads();
-    if (threadIdx.x < 3)
-        atomicOr(&out6[threadIdx.x], acc[threadIdx.x]);
-    else if (threadIdx.x < 6)
-        atomicAnd(&out6[threadIdx.x], acc[threadIdx.x]);
+    if (threadIdx.x < 3 || threadIdx.x == 7)
+        atomicOr(&out8[threadIdx.x], acc[threadIdx.x]);
+    else if (threadIdx.x < 7)
+        atomicAnd(&out8[threadIdx.x], acc[threadIdx.x]);
 }
 
-// The sort key of part 1 as one bit string: barcode id, then the bits of the three UMI words that differ anywhere, most
-// significant first.  Dropping bits that are equal in every row keeps the order of any two rows.  The host cuts the
-// string into runs of adjacent source bits; no run crosses bit 64 of the string.
+// The sort key of part 1 as one bit string: barcode id, then what decides the order of two UMIs, most significant
+// first -- per UMI byte either the rank of its symbol (alphabet NUL A C G N T: as many bits as the symbols that occur
+// need) or, for any other UMI, the bits of the three words that differ anywhere.  Dropping what is equal in every row
+// and replacing symbols by their ranks keeps the order of any two rows.  The host cuts the string into runs; no run
+// crosses bit 64 of the string.
 constexpr int kMaxKeyRuns = 56;
 struct KeyRuns {
     uint32_t n;
+    unsigned long long ranks;  // symbol ranks, three bits each, at bit 3 * (byte & 31)
     struct Run {
-        unsigned long long mask;  // of the run's width
+        unsigned long long mask;  // of the run's width in the string
         uint8_t word, src, dst;   // source word (0..2 = UMI words, 3 = barcode id), first source bit, first bit in the string
+        uint8_t symbol;           // 1: the source is one byte, the run holds its rank
     } r[kMaxKeyRuns];
 };
 
@@ -538,7 +565,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(uint64_t n, const uint32
     for (uint32_t k = 0; k < kr.n; ++k) {  // (wave-uniform: the runs come from the kernel arguments)
         const uint32_t w = kr.r[k].word, src = kr.r[k].src, dst = kr.r[k].dst;
         const uint64_t v = w == 0 ? a : w == 1 ? b : w == 2 ? c : (uint64_t)bc;
-        const uint64_t f = (v >> src) & kr.r[k].mask;
+        uint64_t f = v >> src;
+        if (kr.r[k].symbol) f = kr.ranks >> (3u * ((uint32_t)f & 31u));
+        f &= kr.r[k].mask;
         if (dst < 64u)
             lo |= f << dst;
         else
@@ -1325,39 +1354,68 @@ int tec_sc_expect_records(tec_ctx* ctx, uint64_t n_records) {
 namespace {
 
 // Part 1, step 1: stable LSD radix sort of a permutation by (bcid, u0, u1, u2); sorted views; key heads.
-// The key string of part 1 (see KeyRuns) from the bits that differ: UMI word 2 lowest, then word 1, word 0, the barcode
-// id on top.  False when the string is longer than 96 bits or needs more runs than KeyRuns holds (UMIs of many arbitrary
-// bytes): the caller then sorts column by column.
-bool build_key_runs(const unsigned long long vary[3], unsigned bc_bits, KeyRuns* kr, unsigned* total_bits) {
+// The key string of part 1 (see KeyRuns): UMI word 2 lowest, then word 1, word 0, the barcode id on top.  h8 = what
+// umi_masks_kernel found.  False when the string is longer than 96 bits or needs more runs than KeyRuns holds (long
+// UMIs of arbitrary bytes): the caller then sorts column by column.
+bool build_key_runs(const unsigned long long h8[8], unsigned bc_bits, KeyRuns* kr, unsigned* total_bits) {
+    const unsigned long long vary[3] = {h8[0] & ~h8[3], h8[1] & ~h8[4], h8[2] & ~h8[5]};
     unsigned dst = 0;
     kr->n = 0;
-    auto push = [&](unsigned word, unsigned src, unsigned width) {
+    kr->ranks = 0;
+    auto push = [&](unsigned word, unsigned src, unsigned width, bool symbol) {
         while (width) {
             unsigned take = width;
-            if (dst < 64u && dst + take > 64u) take = 64u - dst;  // no run crosses bit 64 of the string
+            if (dst < 64u && dst + take > 64u) {  // no run crosses bit 64 of the string
+                if (symbol)
+                    dst = 64u;
+                else
+                    take = 64u - dst;
+            }
             if (kr->n == (uint32_t)kMaxKeyRuns || dst + take > 96u) return false;
             KeyRuns::Run& r = kr->r[kr->n++];
             r.mask = take == 64u ? ~0ull : (1ull << take) - 1ull;
             r.word = (uint8_t)word;
             r.src = (uint8_t)src;
             r.dst = (uint8_t)dst;
+            r.symbol = symbol ? 1 : 0;
             src += take;
             dst += take;
             width -= take;
         }
         return true;
     };
-    for (int w = 2; w >= 0; --w) {
-        unsigned long long m = vary[w];
-        while (m) {
-            const unsigned first = (unsigned)__builtin_ctzll(m);
-            const unsigned long long t = m >> first;
-            const unsigned len = t == ~0ull ? 64u : (unsigned)__builtin_ctzll(~t);
-            if (!push((unsigned)w, first, len)) return false;
-            m = len == 64u ? 0ull : m & ~(((1ull << len) - 1ull) << first);
+    if (h8[6]) {
+        // every byte is NUL or a letter of ACGNT: a byte position that varies takes the rank of its symbol among the
+        // symbols that occur at such positions.  (A letter has bit 6 set, so NUL occurs at a position iff the AND of
+        // its bytes has bit 6 clear.)
+        static const unsigned lo5[6] = {0u, 1u, 3u, 7u, 14u, 20u};  // NUL A C G N T, ascending byte values
+        bool nul = false;
+        for (int w = 0; w < 3; ++w)
+            for (int k = 0; k < 8; ++k)
+                if (((vary[w] >> (8 * k)) & 0xFFu) && !((h8[3 + w] >> (8 * k)) & 0x40u)) nul = true;
+        unsigned n_sym = 0;
+        for (int y = 0; y < 6; ++y) {
+            const bool occurs = y == 0 ? nul : ((h8[7] >> lo5[y]) & 1u) != 0;
+            if (occurs) kr->ranks |= (unsigned long long)n_sym++ << (3u * lo5[y]);
+        }
+        const unsigned sym_bits = n_sym <= 2 ? 1u : n_sym <= 4 ? 2u : 3u;
+        for (int w = 2; w >= 0; --w)
+            for (int k = 0; k < 8; ++k)
+                if ((vary[w] >> (8 * k)) & 0xFFu)
+                    if (!push((unsigned)w, 8u * (unsigned)k, sym_bits, true)) return false;
+    } else {
+        for (int w = 2; w >= 0; --w) {
+            unsigned long long m = vary[w];
+            while (m) {
+                const unsigned first = (unsigned)__builtin_ctzll(m);
+                const unsigned long long t = m >> first;
+                const unsigned len = t == ~0ull ? 64u : (unsigned)__builtin_ctzll(~t);
+                if (!push((unsigned)w, first, len, false)) return false;
+                m = len == 64u ? 0ull : m & ~(((1ull << len) - 1ull) << first);
+            }
         }
     }
-    if (!push(3u, 0u, bc_bits)) return false;
+    if (!push(3u, 0u, bc_bits, false)) return false;
     *total_bits = dst;
     return true;
 }
@@ -1437,15 +1495,14 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
     if (by_rows) {
         // the bits that differ among the survivors' UMIs
         SC_HIP(s->marks.reserve(64));
-        const unsigned long long init[6] = {0ull, 0ull, 0ull, ~0ull, ~0ull, ~0ull};
-        unsigned long long h[6];
+        const unsigned long long init[8] = {0ull, 0ull, 0ull, ~0ull, ~0ull, ~0ull, ~0ull, 0ull};
+        unsigned long long h[8];
         SC_HIP(hipMemcpyAsync(s->marks.p, init, sizeof init, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(umi_masks_kernel, dim3(std::min(g, 1024u)), dim3(256), 0, st, N, s->u0.p, s->u1.p, s->u2.p,
                            reinterpret_cast<unsigned long long*>(s->marks.p));
         SC_HIP(hipMemcpyAsync(h, s->marks.p, sizeof h, hipMemcpyDeviceToHost, st));
         SC_HIP(hipStreamSynchronize(st));
-        const unsigned long long vary[3] = {h[0] & ~h[3], h[1] & ~h[4], h[2] & ~h[5]};
-        by_rows = build_key_runs(vary, bits_for(s->n_wl), &kr, &key_bits);
+        by_rows = build_key_runs(h, bits_for(s->n_wl), &kr, &key_bits);
     }
     s->sort_key_bits = by_rows ? key_bits : 0u;
     if (!by_rows) {
@@ -2185,11 +2242,19 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
                            s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, (uint32_t*)nullptr, emoff.p,
                            keys.p, (uint32_t*)nullptr, s->stat.p, scal.p + 1);
         hipLaunchKernelGGL(map_names_kernel, dim3(grid_for(n_keys)), dim3(kB), 0, st, n_keys, keys.p, ctx->d_int2ext);
+        // keys = cell << 32 | name: the name ids use the low bits_for(names) bits only, so the sort runs over the name bits
+        // and then (stable) over the cell bits instead of over all 32 + bits_for(cells)
         size_t bytes = 0;
-        const unsigned kb = 32 + bits_for(s->n_wl);
-        SC_TRY(rocprim::radix_sort_keys(nullptr, bytes, keys.p, keys2.p, n_keys, 0, kb, st));
+        const unsigned nb_name = std::min(32u, bits_for(ctx->idx.n_names)), nb_cell = bits_for(s->n_wl);
+        SC_TRY(rocprim::radix_sort_keys(nullptr, bytes, keys.p, keys2.p, n_keys, 0, nb_name, st));
         SC_TRY(s->tmp.reserve(bytes));
-        SC_TRY(rocprim::radix_sort_keys(s->tmp.p, bytes, keys.p, keys2.p, n_keys, 0, kb, st));
+        SC_TRY(rocprim::radix_sort_keys(s->tmp.p, bytes, keys.p, keys2.p, n_keys, 0, nb_name, st));
+        bytes = 0;
+        SC_TRY(rocprim::radix_sort_keys(nullptr, bytes, keys2.p, keys.p, n_keys, 32, 32 + nb_cell, st));
+        SC_TRY(s->tmp.reserve(bytes));
+        SC_TRY(rocprim::radix_sort_keys(s->tmp.p, bytes, keys2.p, keys.p, n_keys, 32, 32 + nb_cell, st));
+        std::swap(keys.p, keys2.p);
+        std::swap(keys.cap, keys2.cap);
         SC_TRY(ukeys.reserve(n_keys));
         SC_TRY(nemit.reserve(n_keys));
         bytes = 0;

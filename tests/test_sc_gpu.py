@@ -82,19 +82,27 @@ def test_random_vs_oracle(seed, strand, thr, tmp_path):
     assert (tsv, freq) == orc.format_sc_tsv(want_res, want_bc, 25)
 
 
-@pytest.mark.parametrize('umi_len,env,form', [(10, {}, 'one round'), (14, {}, 'two rounds'), (24, {}, 'columns'),
-                                              (10, {'TEC_SC_SORT': 'columns'}, 'columns')])
+WIDE = str.maketrans('ACGTN', 'acgtn')  # UMI bytes outside the NUL / ACGNT alphabet: five bits of a byte differ
+
+
+@pytest.mark.parametrize('umi_len,wide,env,form', [(10, False, {}, 'one round'), (24, False, {}, 'two rounds'),
+                                                   (10, True, {}, 'one round'), (14, True, {}, 'two rounds'),
+                                                   (24, True, {}, 'columns'), (10, False, {'TEC_SC_SORT': 'columns'}, 'columns')])
 @pytest.mark.parametrize('thr', [10 ** 7, 450])
-def test_every_form_of_the_part1_sort(umi_len, env, form, thr, tmp_path, monkeypatch):
-    """Part 1 orders the survivors by (barcode, UMI) through a key string without the bits that are equal in all of
-    them: up to 64 bits in one radix round, up to 96 in two, beyond that (or on request) column by column.  All three
-    forms must give the reference's result (te_count.py:371-476: the dict keyed by 'CB-UB' and its sorted bundles)."""
+def test_every_form_of_the_part1_sort(umi_len, wide, env, form, thr, tmp_path, monkeypatch):
+    """Part 1 orders the survivors by (barcode, UMI) through a key string that leaves out what is equal in all of them
+    (symbol ranks for UMIs over NUL / ACGNT, the differing bits otherwise): up to 64 bits in one radix round, up to 96 in
+    two, beyond that (or on request) column by column.  Every form must give the reference's result (te_count.py:371-476:
+    the dict keyed by 'CB-UB' and its sorted bundles)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     types = ['protein_coding', 'lncRNA', 'TE', 'TE', 'snRNA', 'enhancer', 'miRNA']
     feats = dg.make_features(77, 1200, span=250000, types=types)
     wl = dg.make_whitelist(77, 300)
     recs = dg.make_sc_records(78, 12000, wl, feats, span=250000, n_cells=40, umi_len=umi_len)
+    if wide:
+        for r in recs:
+            r['tags'] = {k: (v.translate(WIDE) if k in ('UB', 'UR') else v) for k, v in r['tags'].items()}
     want_res, want_bc, want_total = orc.sc_count(feats, recs, wl, 20, strand=True, bundle_threshold=thr)
     m, res, tsv, freq = run_sc(FlatIndex.from_features(feats), recs, wl, 20, True, 20, thr, tmp_path, batch_size=2999)
     bits = m.stats['sort_key_bits']
