@@ -544,8 +544,11 @@ struct KeyRuns {
     } r[kMaxKeyRuns];
 };
 
-// One pass over the survivor columns (file order): the 64-byte row of every survivor and its key string (low 64 bits;
-// the bits above them, at most 32, when the string is longer).
+// One pass over the survivor columns (file order): the packed row of every survivor and its key string (low 64 bits;
+// the bits above them, at most 32, when the string is longer).  A string of at most 64 bits says by itself whether two
+// neighbours of the sorted order share their (barcode, UMI), so the row then leaves the UMI out: 32 bytes {record
+// ordinal, barcode id, class, left, rite}; otherwise 64 bytes with the three UMI words in front.
+template <bool WITH_UMI>
 __global__ __launch_bounds__(256) void pack_rows_kernel(uint64_t n, const uint32_t* __restrict__ bcid, const uint64_t* __restrict__ u0,
                                                         const uint64_t* __restrict__ u1, const uint64_t* __restrict__ u2,
                                                         const uint64_t* __restrict__ rec, const int32_t* __restrict__ klass,
@@ -556,11 +559,17 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(uint64_t n, const uint32
     if (i >= n) return;
     const uint64_t a = u0[i], b = u1[i], c = u2[i], o = rec[i];
     const uint32_t bc = bcid[i];
-    uint4* row = rows + 4 * i;
-    row[0] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-    row[1] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)o, (uint32_t)(o >> 32));
-    row[2] = make_uint4(bc, (uint32_t)klass[i], (uint32_t)left[i], (uint32_t)rite[i]);
-    row[3] = make_uint4(0u, 0u, 0u, 0u);
+    if (WITH_UMI) {
+        uint4* row = rows + 4 * i;
+        row[0] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+        row[1] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)o, (uint32_t)(o >> 32));
+        row[2] = make_uint4(bc, (uint32_t)klass[i], (uint32_t)left[i], (uint32_t)rite[i]);
+        row[3] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        uint4* row = rows + 2 * i;
+        row[0] = make_uint4((uint32_t)o, (uint32_t)(o >> 32), bc, (uint32_t)klass[i]);
+        row[1] = make_uint4((uint32_t)left[i], (uint32_t)rite[i], 0u, 0u);
+    }
     uint64_t lo = 0, hi = 0;
     for (uint32_t k = 0; k < kr.n; ++k) {  // (wave-uniform: the runs come from the kernel arguments)
         const uint32_t w = kr.r[k].word, src = kr.r[k].src, dst = kr.r[k].dst;
@@ -574,28 +583,46 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(uint64_t n, const uint32
             hi |= f << (dst - 64u);
     }
     key_lo[i] = lo;
-    if (key_hi) key_hi[i] = (uint32_t)hi;
+    if (WITH_UMI && key_hi) key_hi[i] = (uint32_t)hi;
 }
 
-// The sorted views of part 1: row perm[i] of the packed survivors (one 64-byte piece of one line) spread over the
-// eight sorted columns.  (Eight column gathers pulled eight lines per survivor.)
+// The sorted views of part 1: row perm[i] of the packed survivors (one piece of one line) spread over the sorted
+// columns.  (Eight column gathers pulled eight lines per survivor.)  Rows without the UMI: the first record of every
+// (barcode, UMI) key is marked from the sorted key strings here (ghead_kernel's output); the sorted UMI columns, which
+// nothing else reads, are not written.
+template <bool WITH_UMI>
 __global__ __launch_bounds__(256) void gather_rows_kernel(uint64_t n, const uint32_t* __restrict__ perm, const uint4* __restrict__ rows,
                                                           uint32_t* __restrict__ s_bcid, uint64_t* __restrict__ s_u0,
                                                           uint64_t* __restrict__ s_u1, uint64_t* __restrict__ s_u2,
                                                           uint64_t* __restrict__ s_rec, int32_t* __restrict__ s_klass,
-                                                          int32_t* __restrict__ s_left, int32_t* __restrict__ s_rite) {
+                                                          int32_t* __restrict__ s_left, int32_t* __restrict__ s_rite,
+                                                          const uint64_t* __restrict__ sorted_key, uint8_t* __restrict__ ghead,
+                                                          uint32_t* __restrict__ ghead32) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint4* row = rows + 4 * (uint64_t)perm[i];
-    const uint4 q0 = row[0], q1 = row[1], q2 = row[2];
-    s_u0[i] = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
-    s_u1[i] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
-    s_u2[i] = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
-    s_rec[i] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
-    s_bcid[i] = q2.x;
-    s_klass[i] = (int32_t)q2.y;
-    s_left[i] = (int32_t)q2.z;
-    s_rite[i] = (int32_t)q2.w;
+    if (WITH_UMI) {
+        const uint4* row = rows + 4 * (uint64_t)perm[i];
+        const uint4 q0 = row[0], q1 = row[1], q2 = row[2];
+        s_u0[i] = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
+        s_u1[i] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+        s_u2[i] = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
+        s_rec[i] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+        s_bcid[i] = q2.x;
+        s_klass[i] = (int32_t)q2.y;
+        s_left[i] = (int32_t)q2.z;
+        s_rite[i] = (int32_t)q2.w;
+    } else {
+        const uint4* row = rows + 2 * (uint64_t)perm[i];
+        const uint4 q0 = row[0], q1 = row[1];
+        s_rec[i] = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
+        s_bcid[i] = q0.z;
+        s_klass[i] = (int32_t)q0.w;
+        s_left[i] = (int32_t)q1.x;
+        s_rite[i] = (int32_t)q1.y;
+        const bool h = i == 0 || sorted_key[i] != sorted_key[i - 1];
+        ghead[i] = h;
+        ghead32[i] = h;
+    }
 }
 
 __global__ void ghead_kernel(uint64_t n, const uint32_t* __restrict__ bc, const uint64_t* __restrict__ u0,
@@ -1492,6 +1519,7 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
     bool by_rows = !(how && !strcmp(how, "columns"));
     KeyRuns kr;
     unsigned key_bits = 0;
+    bool heads_done = false;
     if (by_rows) {
         // the bits that differ among the survivors' UMIs
         SC_HIP(s->marks.reserve(64));
@@ -1509,29 +1537,42 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
         int rc = sc_sort_by_columns(ctx, s);
         if (rc) return rc;
     } else {
-        SC_HIP(s->rows.reserve(4 * N));
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(g), dim3(256), 0, st, N, s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p, s->klass.p,
-                           s->left.p, s->rite.p, kr, s->rows.p, s->k64a.p, key_bits > 64u ? s->k32a.p : nullptr);
+        const bool with_umi = key_bits > 64u;
+        SC_HIP(s->rows.reserve((with_umi ? 4 : 2) * N));
+        SC_HIP(s->ghead.reserve(N));
+        if (with_umi)
+            hipLaunchKernelGGL(pack_rows_kernel<true>, dim3(g), dim3(256), 0, st, N, s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p,
+                               s->klass.p, s->left.p, s->rite.p, kr, s->rows.p, s->k64a.p, s->k32a.p);
+        else
+            hipLaunchKernelGGL(pack_rows_kernel<false>, dim3(g), dim3(256), 0, st, N, s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p,
+                               s->klass.p, s->left.p, s->rite.p, kr, s->rows.p, s->k64a.p, (uint32_t*)nullptr);
         int rc = sort_pairs(ctx, s, s->k64a.p, s->k64b.p, s->perm.p, s->perm2.p, N, 0, std::min(key_bits, 64u));
         if (rc) return rc;
         std::swap(s->perm.p, s->perm2.p);
         std::swap(s->perm.cap, s->perm2.cap);
-        if (key_bits > 64u) {
+        if (with_umi) {
             hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, s->perm.p, s->k32a.p, s->k32b.p);
             rc = sort_pairs(ctx, s, s->k32b.p, s->k32a.p, s->perm.p, s->perm2.p, N, 0, key_bits - 64u);
             if (rc) return rc;
             std::swap(s->perm.p, s->perm2.p);
             std::swap(s->perm.cap, s->perm2.cap);
+            hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(g), dim3(256), 0, st, N, s->perm.p, s->rows.p, s->s_bcid.p, s->s_u0.p,
+                               s->s_u1.p, s->s_u2.p, s->s_rec.p, s->s_klass.p, s->s_left.p, s->s_rite.p, (const uint64_t*)nullptr,
+                               (uint8_t*)nullptr, (uint32_t*)nullptr);
+        } else {
+            hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(g), dim3(256), 0, st, N, s->perm.p, s->rows.p, s->s_bcid.p, s->s_u0.p,
+                               s->s_u1.p, s->s_u2.p, s->s_rec.p, s->s_klass.p, s->s_left.p, s->s_rite.p, s->k64b.p, s->ghead.p,
+                               s->k32a.p);
+            heads_done = true;
         }
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(g), dim3(256), 0, st, N, s->perm.p, s->rows.p, s->s_bcid.p, s->s_u0.p, s->s_u1.p,
-                           s->s_u2.p, s->s_rec.p, s->s_klass.p, s->s_left.p, s->s_rite.p);
     }
     SC_HIP(hipGetLastError());
     // ---- keys (groups)
     SC_HIP(s->ghead.reserve(N));
     SC_HIP(s->gid.reserve(N));
-    hipLaunchKernelGGL(ghead_kernel, dim3(g), dim3(kB), 0, st, N, s->s_bcid.p, s->s_u0.p, s->s_u1.p, s->s_u2.p, s->ghead.p,
-                       s->k32a.p);
+    if (!heads_done)
+        hipLaunchKernelGGL(ghead_kernel, dim3(g), dim3(kB), 0, st, N, s->s_bcid.p, s->s_u0.p, s->s_u1.p, s->s_u2.p, s->ghead.p,
+                           s->k32a.p);
     int rc = scan_u32(ctx, s, s->k32a.p, s->gid.p, N, true, rocprim::plus<uint32_t>());
     if (rc) return rc;
     uint32_t last_gid = 0;
