@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void count_bulk_kernel(tec_index_dev idx, c
 // ---------------------------------------------------------------------------------------------
 // Record kernel: one compact bin record per edge lookup (index.hip), hits collected in registers.
 
-// Compact bin record (index.hip): {n, off, NE x {left16 | right16 << 16, meta}}; coordinates are
+// Compact bin record (index.hip): {n, off, NE x {left16 | width16 << 16, meta}}; left and right = left + width are
 // relative to (bin start - 1) and clamped to the bin, which is all the two edge tests need for a
 // position inside the bin.  NE = 3 -> 32 bytes (two 16-byte gathers), NE = 7 -> 64 bytes.
 template <int NE>
@@ -507,37 +507,40 @@ __device__ __forceinline__ uint4 load_piece(const uint4* __restrict__ cont, uint
 }
 
 // Edge tests of one list for a unit that is NOT on a 10 kb boundary (every hit is then a bucket
-// candidate, see is_candidate).  t1_on / t2_on: is p1 / p2 inside this record's bin?  x1 / x2 are
-// the positions relative to (bin start - 1).  Inline slots beyond the bin's count are zero and
+// candidate, see is_candidate).  x1 / x2m: p1 and p2 - 1 relative to (bin start - 1), or -1 when
+// that edge does not lie in this record's bin.  Inline slots beyond the bin's count are zero and
 // fail both tests by themselves.  Entries NE..NE+3 arrive as two prefetched continuation pieces
 // (c0, c1: zero when the list is shorter); the branches around them are wave-uniform.  Lists
 // longer than NE + 4 (0.1 % of the hg38-like lookups) walk the rest of their continuation run.
 template <bool MIXED, bool FULL>
-__device__ __forceinline__ void test_compact(uint32_t lr, uint32_t meta, int x1, int x2, bool t1_on, bool t2_on, HitSet& hs) {
-    const int l = (int)(lr & 0xFFFFu), g = (int)(lr >> 16);
-    const bool t1 = t1_on & (x1 >= l) & (x1 < g);
-    const bool t2 = t2_on & (x2 > l) & (x2 <= g);
+__device__ __forceinline__ void test_compact(uint32_t lw, uint32_t meta, int x1, int x2m, HitSet& hs) {
+    // the entry as {left, width = right - left} (16 bits each): p lies in [left, right) iff (unsigned)(p - left) < width.
+    // T1 is x1 in [left, right), T2 is x2 in (left, right] = x2 - 1 in [left, right); a test that is switched off comes
+    // with the position -1, which no entry contains.  Two instructions a test and no scalar mask arithmetic (the form
+    // with four compares needed five scalar operations a slot on the unit that the CU's four SIMDs share).
+    const uint32_t l = lw & 0xFFFFu, w = lw >> 16;
+    const bool t1 = (uint32_t)x1 - l < w;
+    const bool t2 = (uint32_t)x2m - l < w;
     hs.add_if<MIXED, FULL>(t1 | t2, meta);
 }
 
 template <int NE, bool MIXED, bool FULL>
 __device__ __forceinline__ void scan_record(const BinRec<NE>& r, const uint4 c0, const uint4 c1,
-                                            const uint4* __restrict__ cont, int x1, int x2, bool t1_on, bool t2_on,
-                                            HitSet& hs) {
+                                            const uint4* __restrict__ cont, int x1, int x2m, HitSet& hs) {
 #pragma unroll
-    for (int k = 0; k < NE; ++k) test_compact<MIXED, FULL>(r.lr[k], r.meta[k], x1, x2, t1_on, t2_on, hs);
+    for (int k = 0; k < NE; ++k) test_compact<MIXED, FULL>(r.lr[k], r.meta[k], x1, x2m, hs);
     if (__builtin_amdgcn_ballot_w64(r.n > (uint32_t)NE) == 0) return;
-    test_compact<MIXED, FULL>(c0.x, c0.y, x1, x2, t1_on, t2_on, hs);
-    test_compact<MIXED, FULL>(c0.z, c0.w, x1, x2, t1_on, t2_on, hs);
+    test_compact<MIXED, FULL>(c0.x, c0.y, x1, x2m, hs);
+    test_compact<MIXED, FULL>(c0.z, c0.w, x1, x2m, hs);
     if (__builtin_amdgcn_ballot_w64(r.n > (uint32_t)NE + 2u) == 0) return;
-    test_compact<MIXED, FULL>(c1.x, c1.y, x1, x2, t1_on, t2_on, hs);
-    test_compact<MIXED, FULL>(c1.z, c1.w, x1, x2, t1_on, t2_on, hs);
+    test_compact<MIXED, FULL>(c1.x, c1.y, x1, x2m, hs);
+    test_compact<MIXED, FULL>(c1.z, c1.w, x1, x2m, hs);
     if (r.n > (uint32_t)NE + 4u) {
         const uint32_t pieces = (r.n - (uint32_t)NE + 1u) >> 1;
         for (uint32_t j = 2; j < pieces; ++j) {
             const uint4 c = load_piece(cont, r.off + j);
-            test_compact<MIXED, FULL>(c.x, c.y, x1, x2, t1_on, t2_on, hs);
-            test_compact<MIXED, FULL>(c.z, c.w, x1, x2, t1_on, t2_on, hs);
+            test_compact<MIXED, FULL>(c.x, c.y, x1, x2m, hs);
+            test_compact<MIXED, FULL>(c.z, c.w, x1, x2m, hs);
         }
     }
 }
@@ -708,8 +711,10 @@ __global__ __launch_bounds__(kBlock, TEC_REC_WAVES) void count_bulk_rec_kernel(t
                          (unsigned)u.p2 + 1u == q2 * TEC_BUCKET_SIZE;
             HitSet hs{kNoName, kNoName, kNoName, kNoName, kNoName, kNoName, 0u, 0u};
             if (!u.boundary) {
-                scan_record<NE, MIXED, false>(ra[k], ca0[k], ca1[k], idx.cont, xa1[k], xa2[k], true, one[k], hs);
-                scan_record<NE, MIXED, true>(rb[k], cb0[k], cb1[k], idx.cont, 0, xb2[k], false, true, hs);
+                // (positions relative to bin start - 1; the second test of a record sees x2 - 1, a test that does not
+                // apply to the record sees -1)
+                scan_record<NE, MIXED, false>(ra[k], ca0[k], ca1[k], idx.cont, xa1[k], one[k] ? xa2[k] - 1 : -1, hs);
+                scan_record<NE, MIXED, true>(rb[k], cb0[k], cb1[k], idx.cont, -1, xb2[k] - 1, hs);
             }
             // exact CSR walk for the rare rest: p1 or p2+1 on a 10 kb boundary (the reference's
             // bucket-candidate rule can bite there), or more than six distinct names

@@ -9,7 +9,7 @@
 //   entries[n_entries]    {left, right, meta, pad} 16 B, sorted by (name id, strand) inside a fine bin
 //   chrom_base[n_chrom], chrom_nbins[n_chrom]
 //   recs[n_bins]          compact bin records for the bulk kernel: {n = entries in the bin,
-//                         coff, the bin's first NE entries as {left16 | right16<<16, meta}} with
+//                         coff, the bin's first NE entries as {left16 | width16<<16, meta}} with
 //                         coordinates relative to (bin start - 1) and clamped to the bin -- 32
 //                         bytes for NE = 3.  One record answers an edge lookup for every bin with
 //                         at most NE entries (one dependent gather level instead of two).
@@ -254,7 +254,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
     RawBuf<uint32_t> recs((size_t)(n_bins + 1) * rec_words + 4);  // + one all-zero record (idx.zero_rec)
     for (size_t k = (size_t)n_bins * rec_words; k < recs.size(); ++k) recs[k] = 0u;
     uint64_t n_pieces = 0;
-    std::vector<uint32_t> cont;  // 4 words per piece = two {left16 | right16<<16, meta} entries
+    std::vector<uint32_t> cont;  // 4 words per piece = two {left16 | width16<<16, meta} entries
     if (rec_ne) {
         uint64_t pieces = 0;
         for (uint64_t b = 0; b < n_bins; ++b) {
@@ -302,7 +302,7 @@ extern "C" int tec_index_build(tec_ctx* ctx, uint64_t n, const int32_t* chrom_id
                     const int64_t l = std::min<int64_t>(std::max<int64_t>((int64_t)entries[a + k].left - start + 1, 0), width + 2);
                     const int64_t g = std::min<int64_t>(std::max<int64_t>((int64_t)entries[a + k].right - start + 1, 0), width + 2);
                     uint32_t* w = k < (uint32_t)rec_ne ? &r[2 + 2 * k] : &cont[(size_t)piece * 4 + 2 * (k - rec_ne)];
-                    w[0] = (uint32_t)l | ((uint32_t)g << 16);
+                    w[0] = (uint32_t)l | ((uint32_t)std::max<int64_t>(g - l, 0) << 16);  // {left, width}: see test_compact (bulk.hip)
                     w[1] = entries[a + k].meta;
                 }
                 piece += pieces_of(b);

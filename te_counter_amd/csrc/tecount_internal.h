@@ -26,7 +26,7 @@ struct tec_index_dev {
     const tec_entry* entries;     // [n_entries], sorted by name id inside each fine bin
     const uint32_t* chrom_base;   // [n_chrom] first fine bin of each chromosome
     const uint32_t* chrom_nbins;  // [n_chrom] number of fine bins of each chromosome
-    const uint4* recs;            // [n_bins] compact bin records {n, coff, NE x {left16|right16<<16, meta}}: see index.hip
+    const uint4* recs;            // [n_bins] compact bin records {n, coff, NE x {left16|width16<<16, meta}}: see index.hip
     const uint4* cont;            // continuation pieces (two compact entries each) of bins with more than NE entries
     uint32_t zero_rec;            // index of an all-zero record behind the table (n_bins)
     uint32_t zero_piece;          // index of an all-zero continuation piece behind the table
