@@ -109,7 +109,7 @@ struct ScBuffers {
     struct {
         dvec<uint32_t> sel, selprefix, lines, lkeys, lkeys2, lines2, firstkept, qflag, qscan, qrec, nemit, emoff, cellhits, present, pred;
         dvec<uint8_t> kept_rec;
-        dvec<uint64_t> keys, keys2, ukeys;
+        dvec<uint64_t> keys, keys2, ukeys, side;
         dvec<unsigned long long> scal;
     } p23;
     // the whitelist the tables in `wl` / `wl_table` were built from: a run with the same barcodes (the usual case: one
@@ -152,7 +152,7 @@ struct ScBuffers {
     void free_all() {
         p23.sel.release(); p23.selprefix.release(); p23.lines.release(); p23.lkeys.release(); p23.lkeys2.release(); p23.lines2.release();
         p23.firstkept.release(); p23.qflag.release(); p23.qscan.release(); p23.qrec.release(); p23.nemit.release(); p23.emoff.release();
-        p23.cellhits.release(); p23.kept_rec.release(); p23.keys.release(); p23.keys2.release(); p23.ukeys.release(); p23.scal.release();
+        p23.cellhits.release(); p23.kept_rec.release(); p23.keys.release(); p23.keys2.release(); p23.ukeys.release(); p23.side.release(); p23.scal.release();
         p23.present.release(); p23.pred.release();
         deal.release();
         land.release();
@@ -730,12 +730,12 @@ __global__ __launch_bounds__(256) void part1_count_kernel(uint64_t n, const uint
     }
 }
 
-__global__ void flag_from_u8_kernel(uint64_t n, const uint8_t* __restrict__ f, uint32_t* out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f[i];
-}
+struct U8ToU32 {
+    __host__ __device__ uint32_t operator()(uint8_t v) const { return v; }
+};
 
-__global__ void compact_idx_kernel(uint64_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan,
+template <class F>
+__global__ void compact_idx_kernel(uint64_t n, const F* __restrict__ flag, const uint32_t* __restrict__ scan,
                                    uint32_t* out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flag[i]) out[scan[i]] = (uint32_t)i;
@@ -864,12 +864,15 @@ __device__ __forceinline__ void sc_range(const tec_index_dev& idx, int chrom, in
 
 // Part 3 for one (cell, class, left, rite).  EMIT=false: returns the number of (cell, name)
 // increments; EMIT=true: writes them.  Also bumps the per-cell "mapped to something" counter.
+// The counting pass keeps a query's first kSide keys in `side` (key j of query t at side[j * nq + t]): the writing
+// pass copies them to their place and walks the index again only for the queries that emitted more.
+constexpr uint32_t kSide = 4;
 template <bool EMIT>
 __global__ __launch_bounds__(256) void sc_query_kernel(tec_index_dev idx, uint64_t nq, const uint32_t* __restrict__ qrec,
                                 const uint32_t* __restrict__ bc, const int32_t* __restrict__ klass,
                                 const int32_t* __restrict__ left, const int32_t* __restrict__ rite,
                                 const int32_t* __restrict__ cls_chrom, int stranded, uint32_t* n_emit,
-                                const uint32_t* __restrict__ emit_off, uint64_t* keys, uint32_t* cellhits,
+                                const uint32_t* __restrict__ emit_off, uint64_t* keys, uint64_t* side, uint32_t* cellhits,
                                 unsigned long long* stat, unsigned long long* n_assigned) {
     // tallies per block (see BlockTally): [0] assigned, [1] hits on a feature without a strand.  A fixed grid strides
     // over the queries in whole-wave steps (every lane of a wave makes the same number of trips: the per-cell adds
@@ -890,7 +893,10 @@ __global__ __launch_bounds__(256) void sc_query_kernel(tec_index_dev idx, uint64
     const int chrom = cls_chrom[kl >> 1];
     uint32_t emitted = 0;
     uint64_t* out = EMIT ? keys + emit_off[t] : nullptr;
-    if (chrom >= 0) {
+    const uint32_t counted = EMIT ? n_emit[t] : 0u;
+    if (EMIT && counted <= kSide) {
+        for (uint32_t j = 0; j < counted; ++j) out[j] = side[(uint64_t)j * nq + t];
+    } else if (chrom >= 0) {
         ScQuery q;
         q.left = left[i];
         q.rite = rite[i];
@@ -935,7 +941,10 @@ __global__ __launch_bounds__(256) void sc_query_kernel(tec_index_dev idx, uint64
                 auto emit = [&](uint32_t pair) {
                     // gene branch: antisense pairs are skipped when --strand (te_count.py:665)
                     if (gene && stranded && (pair >> TEC_META_STRAND_SHIFT) != rs) return;
-                    if (EMIT) out[emitted] = cell | (pair & kNameMask);
+                    if (EMIT)
+                        out[emitted] = cell | (pair & kNameMask);
+                    else if (emitted < kSide)
+                        side[(uint64_t)emitted * nq + t] = cell | (pair & kNameMask);
                     ++emitted;
                 };
                 for (uint32_t j = a0; j < a1; ++j) {
@@ -997,8 +1006,8 @@ __global__ void map_names_kernel(uint64_t n, uint64_t* keys, const uint32_t* __r
 
 inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kB - 1) / kB); }
 
-template <class T>
-int scan_u32(tec_ctx* ctx, tec_sc_state* s, const uint32_t* in, uint32_t* out, size_t n, bool inclusive, T op) {
+template <class In, class T>
+int scan_u32(tec_ctx* ctx, tec_sc_state* s, In in, uint32_t* out, size_t n, bool inclusive, T op) {
     size_t bytes = 0;
     if (inclusive)
         SC_HIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, op, ctx->s_compute));
@@ -1012,8 +1021,8 @@ int scan_u32(tec_ctx* ctx, tec_sc_state* s, const uint32_t* in, uint32_t* out, s
     return TEC_OK;
 }
 
-template <class K>
-int sort_pairs(tec_ctx* ctx, tec_sc_state* s, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
+template <class K, class VIn>
+int sort_pairs(tec_ctx* ctx, tec_sc_state* s, const K* kin, K* kout, VIn vin, uint32_t* vout, size_t n,
                unsigned b0, unsigned b1) {
     size_t bytes = 0;
     SC_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, b0, b1, ctx->s_compute));
@@ -1454,6 +1463,7 @@ int sc_sort_by_columns(tec_ctx* ctx, tec_sc_state* s) {
     hipStream_t st = ctx->s_compute;
     const uint64_t N = s->n_live;
     const unsigned g = grid_for(N);
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p);
     const uint64_t* words[3] = {s->u2.p, s->u1.p, s->u0.p};
     const unsigned long long masks[3] = {s->h_stat[ST_OR2], s->h_stat[ST_OR1], s->h_stat[ST_OR0]};
     for (int w = 0; w < 3; ++w) {
@@ -1514,7 +1524,6 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
     SC_HIP(s->s_klass.reserve(N));
     SC_HIP(s->s_left.reserve(N));
     SC_HIP(s->s_rite.reserve(N));
-    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kB), 0, st, N, s->perm.p);
     const char* how = getenv("TEC_SC_SORT");  // "columns": the column-by-column rounds for every input
     bool by_rows = !(how && !strcmp(how, "columns"));
     KeyRuns kr;
@@ -1546,7 +1555,8 @@ int sc_part1_sort(tec_ctx* ctx, tec_sc_state* s) {
         else
             hipLaunchKernelGGL(pack_rows_kernel<false>, dim3(g), dim3(256), 0, st, N, s->bcid.p, s->u0.p, s->u1.p, s->u2.p, s->rec.p,
                                s->klass.p, s->left.p, s->rite.p, kr, s->rows.p, s->k64a.p, (uint32_t*)nullptr);
-        int rc = sort_pairs(ctx, s, s->k64a.p, s->k64b.p, s->perm.p, s->perm2.p, N, 0, std::min(key_bits, 64u));
+        // (the values are the row numbers 0, 1, 2 ...: an iterator, not an array)
+        int rc = sort_pairs(ctx, s, s->k64a.p, s->k64b.p, rocprim::counting_iterator<uint32_t>(0u), s->perm2.p, N, 0, std::min(key_bits, 64u));
         if (rc) return rc;
         std::swap(s->perm.p, s->perm2.p);
         std::swap(s->perm.cap, s->perm2.cap);
@@ -2054,19 +2064,18 @@ int sc_lines(tec_ctx* ctx, tec_sc_state* s, dvec<uint32_t>& lines, dvec<uint32_t
     hipStream_t st = ctx->s_compute;
     const uint64_t N = s->n_live;
     const unsigned g = grid_for(N);
-    SC_HIP(s->k32a.reserve(N));
     SC_HIP(s->k32b.reserve(N));
-    hipLaunchKernelGGL(flag_from_u8_kernel, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->k32a.p);
-    int rc = scan_u32(ctx, s, s->k32a.p, s->k32b.p, N, false, rocprim::plus<uint32_t>());
+    int rc = scan_u32(ctx, s, rocprim::make_transform_iterator(s->ihead.p, U8ToU32()), s->k32b.p, N, false, rocprim::plus<uint32_t>());
     if (rc) return rc;
-    uint32_t ls = 0, lf = 0;
+    uint32_t ls = 0;
+    uint8_t lf = 0;
     SC_HIP(hipMemcpyAsync(&ls, s->k32b.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
-    SC_HIP(hipMemcpyAsync(&lf, s->k32a.p + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    SC_HIP(hipMemcpyAsync(&lf, s->ihead.p + (N - 1), 1, hipMemcpyDeviceToHost, st));
     SC_HIP(hipStreamSynchronize(st));
-    const uint64_t n_lines = (uint64_t)ls + lf;
+    const uint64_t n_lines = (uint64_t)ls + (lf ? 1u : 0u);
     *n_lines_out = n_lines;
     SC_HIP(lines.reserve(n_lines));
-    hipLaunchKernelGGL(compact_idx_kernel, dim3(g), dim3(kB), 0, st, N, s->k32a.p, s->k32b.p, lines.p);
+    hipLaunchKernelGGL(compact_idx_kernel<uint8_t>, dim3(g), dim3(kB), 0, st, N, s->ihead.p, s->k32b.p, lines.p);
     if (s->n_epochs > 1) {
         SC_HIP(lkeys.reserve(n_lines));
         SC_HIP(lkeys2.reserve(n_lines));
@@ -2154,7 +2163,7 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
                   &firstkept = B.firstkept, &qflag = B.qflag, &qscan = B.qscan, &qrec = B.qrec, &nemit = B.nemit, &emoff = B.emoff,
                   &cellhits = B.cellhits, &present = B.present, &pred = B.pred;
     dvec<uint8_t>& kept_rec = B.kept_rec;
-    dvec<uint64_t>&keys = B.keys, &keys2 = B.keys2, &ukeys = B.ukeys;
+    dvec<uint64_t>&keys = B.keys, &keys2 = B.keys2, &ukeys = B.ukeys, &side = B.side;
     dvec<unsigned long long>& scal = B.scal;
     auto cleanup = [&]() {};
 #define SC_TRY(call)                         \
@@ -2240,14 +2249,15 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
         return TEC_OK;
     }
     SC_TRY(qrec.reserve(nq));
-    hipLaunchKernelGGL(compact_idx_kernel, dim3(g), dim3(kB), 0, st, N, qflag.p, qscan.p, qrec.p);
+    hipLaunchKernelGGL(compact_idx_kernel<uint32_t>, dim3(g), dim3(kB), 0, st, N, qflag.p, qscan.p, qrec.p);
     SC_TRY(nemit.reserve(nq));
     SC_TRY(emoff.reserve(nq));
+    SC_TRY(side.reserve((size_t)kSide * nq));
     SC_TRY(cellhits.reserve(s->n_wl));
     SC_TRY(hipMemsetAsync(cellhits.p, 0, (size_t)s->n_wl * 4, st));
     hipLaunchKernelGGL(sc_query_kernel<false>, dim3(std::min(grid_for(nq), 4096u)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
                        s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, nemit.p, (const uint32_t*)nullptr,
-                       (uint64_t*)nullptr, cellhits.p, s->stat.p, scal.p + 1);
+                       (uint64_t*)nullptr, side.p, cellhits.p, s->stat.p, scal.p + 1);
     SC_RC(scan_u32(ctx, s, nemit.p, emoff.p, nq, false, rocprim::plus<uint32_t>()));
     uint32_t es = 0, ef = 0;
     SC_TRY(hipMemcpyAsync(&es, emoff.p + (nq - 1), 4, hipMemcpyDeviceToHost, st));
@@ -2280,8 +2290,8 @@ static int sc_part23_impl(tec_ctx* ctx, uint32_t n_selected, const uint32_t* sel
         SC_TRY(keys.reserve(n_keys));
         SC_TRY(keys2.reserve(n_keys));
         hipLaunchKernelGGL(sc_query_kernel<true>, dim3(std::min(grid_for(nq), 4096u)), dim3(kB), 0, st, ctx->idx, nq, qrec.p, s->s_bcid.p,
-                           s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, (uint32_t*)nullptr, emoff.p,
-                           keys.p, (uint32_t*)nullptr, s->stat.p, scal.p + 1);
+                           s->s_klass.p, s->s_left.p, s->s_rite.p, s->cls_chrom.p, s->stranded, nemit.p, emoff.p,
+                           keys.p, side.p, (uint32_t*)nullptr, s->stat.p, scal.p + 1);
         hipLaunchKernelGGL(map_names_kernel, dim3(grid_for(n_keys)), dim3(kB), 0, st, n_keys, keys.p, ctx->d_int2ext);
         // keys = cell << 32 | name: the name ids use the low bits_for(names) bits only, so the sort runs over the name bits
         // and then (stable) over the cell bits instead of over all 32 + bits_for(cells)
