@@ -7,11 +7,12 @@
 // HBM (32-48 B per record: 288 GB holds billions), and the three parts become whole-array
 // passes:
 //
-//   submit   filters (te_count.py:394-433): flags, mapq, CB|CR present, whitelist lookup (binary
-//            lookup in the sorted, byte-packed whitelist -> id = rank, te_count.py:338,418),
+//   submit   filters (te_count.py:394-433): flags, mapq, CB|CR present, whitelist lookup (hash
+//            table over the sorted, byte-packed whitelist -> id = rank, te_count.py:338,418),
 //            UB|UR present, '_'/'alt' chromosomes; order-preserving compaction of survivors
-//   part 1   stable LSD radix sort by (barcode id, UMI bytes) -> records of one key are adjacent
-//            and in file order.  Epochs ("bundles", te_count.py:377-390) are recovered exactly:
+//   part 1   stable radix sort by (barcode id, UMI bytes) -- through a key string without the bits
+//            that are equal in every survivor, and one gather of packed rows (sc_part1_sort) ->
+//            records of one key are adjacent and in file order.  Epochs ("bundles", te_count.py:377-390) are recovered exactly:
 //            the epoch ends at the record that creates the bundle_keys-th distinct key since the
 //            last flush.  Inside an (epoch, key) instance the first record supplies the stored
 //            string; later records of the same class are duplicates (te_count.py:452-454), a
