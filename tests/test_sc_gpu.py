@@ -117,6 +117,25 @@ def test_every_form_of_the_part1_sort(umi_len, wide, env, form, thr, tmp_path, m
     assert (tsv, freq) == orc.format_sc_tsv(want_res, want_bc, 20)
 
 
+def test_sort_key_bits_needs_the_sort(tmp_path):
+    """tec_sc_sort_key_bits before tec_sc_part1_sort is a state error, not a stale number."""
+    import numpy as np
+    from te_counter_amd import Engine
+    feats = dg.make_features(5, 50)
+    eng = Engine(0)
+    eng.upload_index(FlatIndex.from_features(feats))
+    wl24 = np.zeros((2, 24), np.uint8)
+    wl24[0, :4] = np.frombuffer(b'AAAC', np.uint8)
+    wl24[1, :4] = np.frombuffer(b'AAAG', np.uint8)
+    eng.sc_begin(False, 20, wl24, 10 ** 7, np.zeros(1, np.int32), np.zeros(1, np.uint8))
+    from te_counter_amd._lib import TecError
+    with pytest.raises(TecError):
+        eng.sc_sort_key_bits()
+    assert eng.sc_part1_sort() == 0 and eng.sc_sort_key_bits() == 0  # no survivors: nothing was sorted
+    eng.sc_end()
+    eng.close()
+
+
 @pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('name', ['sc_rand21_strand_multibundle', 'sc_rand22_nostrand_multibundle', 'sc_topcells_binding_multibundle',
                                   'sc_rand22_strand', 'sc_degenerate_boundary'])
