@@ -162,6 +162,36 @@ def test_config4_full_size_single_cell():
     eng.close()
 
 
+@pytest.mark.parametrize('umi_len,lower,form', [(12, False, 'one round'), (24, False, 'two rounds'), (16, True, 'two rounds')])
+def test_sort_forms_agree_at_3M_records(umi_len, lower, form, monkeypatch):
+    """Part 1's sort through the compact key string (symbol ranks / differing bits, one and two radix rounds) against the
+    column-by-column form on 3 M records (te_count.py:371-476 needs the keys grouped and each key's records in file
+    order; both forms must lead to the same cells, totals and triplets, spill epochs included)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_sc
+    ann = synth.make_annotation('hg38', scale=0.05)
+    eng = Engine(0)
+    eng.upload_index(ann.flat)
+    arrays, wl, tables = synth.make_sc_arrays(ann, 3_000_000, n_cells=500, n_whitelist=100_000, seed=77, umi_len=umi_len)
+    if lower:
+        ub = arrays['ub24']
+        ub[ub != 0] |= 0x20  # lower-case letters: outside the NUL / ACGNT alphabet
+    bits = []
+    end = eng.sc_end
+    monkeypatch.setattr(eng, 'sc_end', lambda: (bits.append(eng.sc_sort_key_bits()), end())[1])
+    out, st, _, _ = bench_sc.run(eng, arrays, wl, tables, 400, True, 400_000)
+    assert {'one round': 0 < bits[-1] <= 64, 'two rounds': 64 < bits[-1] <= 96}[form], bits
+    assert st['bundles'] >= 2
+    monkeypatch.setenv('TEC_SC_SORT', 'columns')
+    out2, st2, _, _ = bench_sc.run(eng, arrays, wl, tables, 400, True, 400_000)
+    assert bits[-1] == 0 and st2 == st
+    for k in ('cells', 'cell_hits', 'coo_cell', 'coo_name', 'coo_count'):
+        assert np.array_equal(out2[k], out[k]), k
+    eng.close()
+
+
 def test_custom_3M_interval_annotation():
     """BASELINE config 5 shape: 3 M unique-name intervals (name space far beyond the LDS
     histogram: the remaining names go through the spill list, sorted and run-length encoded after every
