@@ -17,7 +17,7 @@ At N = 1 the line also carries what a user of te_count sees, all measured in thi
   pcie_inclusive            pinned host batches -> hipMemcpyAsync -> kernel
   end_to_end_from_bam       a synthetic BAM file on disk -> measureTE.parse_bampe -> TSV (+ a 10x-style BAM -> sc_parse_bamse)
   single_cell               BASELINE config 4 (50 M records, 10 k cells) with an oracle sub-check
-  secondary                 BASELINE configs 2 (100 M SE, shuffled and coordinate-sorted) and 5 (3 M names)
+  secondary                 the headline workload coordinate-sorted, BASELINE configs 2 (100 M SE, shuffled and sorted) and 5 (3 M names)
 (`--legs headline` skips them.)
 """
 
@@ -574,19 +574,21 @@ def single_cell(ann, eng, records):
 
 
 def secondary(ann, eng, args):
-    """BASELINE configs 2 and 5 on the count kernel, each with its own roofline; config 3 as named (bulk PE with --strand,
+    """The headline workload in coordinate-sorted order and BASELINE configs 2 and 5 on the count kernel, each with its own
+    roofline; config 3 as named (bulk PE with --strand,
     which the reference refuses: te_count.py:58-59) through the stranded-bulk extension -- no reference output exists for
     it, so that entry says `"pinned": false`."""
     from te_counter_amd import synth
     out = {}
-    for key, a, layout, order, genome in (('config2_100M_SE_hg38_shuffled', ann, 'se', 'shuffled', 'hg38'),
+    for key, a, layout, order, genome in (('headline_125M_PE_hg38_sorted', ann, 'pe', 'sorted', 'hg38'),
+                                          ('config2_100M_SE_hg38_shuffled', ann, 'se', 'shuffled', 'hg38'),
                                           ('config2_100M_SE_hg38_sorted', ann, 'se', 'sorted', 'hg38'),
                                           ('config5_100M_SE_3M_names', None, 'se', 'shuffled', 'custom3m'),
                                           ('config3_125M_PE_mm10_stranded_extension', None, 'pe', 'shuffled', 'mm10')):
         stranded = 'stranded' in key
         if a is None:
             a = synth.make_annotation('mm10') if genome == 'mm10' else synth.make_custom_annotation()
-        run = BulkRun(eng, a, layout, order, 125_000_000 if stranded else 100_000_000,
+        run = BulkRun(eng, a, layout, order, 125_000_000 if layout == 'pe' else 100_000_000,
                       seed={'hg38': 2002, 'mm10': 2003}.get(genome, 2005), stranded=stranded)
         K = 20  # one job = begin, K launches over the resident batch, finish (D2H of the count vector: 24 MB for 3 M names)
         run.count(2)
